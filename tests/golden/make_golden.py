@@ -1,0 +1,403 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by RUNNING the reference (pygenray) in the build container.
+
+TEST INFRASTRUCTURE ONLY.  This script is the only place that imports
+/root/reference; it is run by hand in the build container (the reference does
+not exist on the GPU box) and only its *outputs* (small .npz files of inputs
+and expected outputs) are committed next to it.
+
+The reference needs `numba` and `xarray`, neither of which is installed here
+(SURVEY.md section 8c).  As recorded there, the import works with in-memory
+stand-ins: `numba.njit` -> identity decorator (the reference then runs as
+plain, strictly-IEEE Python - no fastmath re-association) and an empty
+`xarray` module (only used for a type annotation).  The hot path is driven
+through the reference's own functions:
+
+  * pygenray.launch_rays._shoot_ray_array / _interpolate_ray   (array level)
+  * pygenray.launch_rays.shoot_ray / shoot_rays (<70 branch)    via a duck-typed
+    environment object exposing exactly the attributes _unpack_envi reads
+    (reference launch_rays.py:717-742)
+  * pygenray.eigenrays._find_single_eigenray                    (same duck env)
+  * pygenray.integration_processes.*                            (unit vectors)
+
+Usage:  python tests/golden/make_golden.py            (writes tests/golden/*.npz)
+"""
+import os
+import sys
+import types
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_SRC = "/root/reference/src"
+
+
+def _install_standins():
+    sys.dont_write_bytecode = True
+    nb = types.ModuleType("numba")
+
+    def njit(*a, **k):
+        if len(a) == 1 and callable(a[0]) and not k:
+            return a[0]
+        return lambda f: f
+
+    nb.njit = njit
+    sys.modules["numba"] = nb
+    xr = types.ModuleType("xarray")
+
+    class DataArray:  # annotation only (environment.py:240)
+        pass
+
+    xr.DataArray = DataArray
+    sys.modules["xarray"] = xr
+    sys.path.insert(0, REF_SRC)
+
+
+_install_standins()
+import pygenray as pr  # noqa: E402
+from pygenray import launch_rays as lr  # noqa: E402
+from pygenray import eigenrays as er  # noqa: E402
+from pygenray.environment import munk_ssp, eflat  # noqa: E402
+
+
+# --------------------------------------------------------------------------
+# duck-typed environment: just what _unpack_envi / EigenRays touch
+# --------------------------------------------------------------------------
+class _Coord:
+    def __init__(self, v):
+        self.values = np.asarray(v, dtype=float)
+
+
+class _DA:
+    """The handful of xarray.DataArray members the reference reads."""
+
+    def __init__(self, values, **coords):
+        self.values = np.asarray(values, dtype=float)
+        self._coords = {k: np.asarray(v, dtype=float) for k, v in coords.items()}
+        for k, v in self._coords.items():
+            setattr(self, k, _Coord(v))
+
+    def differentiate(self, coord):
+        # xarray.DataArray.differentiate(coord, edge_order=1) == np.gradient
+        assert coord == "depth"
+        return _DA(np.gradient(self.values, self._coords["depth"], axis=1, edge_order=1),
+                   **self._coords)
+
+
+class DuckEnv:
+    def __init__(self, c2d, r, z, bathy, bathy_r, lat=35.0, flat=False):
+        self.sound_speed = _DA(c2d, range=r, depth=z)
+        self.bathymetry = _DA(bathy, range=bathy_r)
+        # environment.py:111-114 (computed from the UNtransformed bathymetry, Q10)
+        slope = np.gradient(np.asarray(bathy, float), np.asarray(bathy_r, float))
+        self.bottom_angle = np.degrees(np.arctan(slope))
+        if flat:
+            # environment.py:121-154 (same depth grid for every column)
+            depf, _ = eflat(np.asarray(z, float), lat, np.asarray(c2d, float)[0])
+            cf = np.array([eflat(np.asarray(z, float), lat, row)[1] for row in np.asarray(c2d, float)])
+            self.sound_speed_fe = _DA(cf, range=r, depth=depf)
+            bf, _ = eflat(np.asarray(bathy, float), lat)
+            self.bathymetry_fe = _DA(bf, range=bathy_r)
+
+
+def env_arrays(env, flatearth=False):
+    return lr._unpack_envi(env, flatearth=flatearth)
+
+
+def shoot_array_level(arrs, source_depth, source_range, receiver_range, theta_ode_deg, S,
+                      rtol=1e-9, terminate_backwards=True):
+    """Exactly what _shoot_single_ray_process does (launch_rays.py:544-576) minus shm."""
+    cin, cpin, rin, zin, depths, depth_ranges, bottom_angles = arrs
+    c = pr.bilinear_interp(source_range, source_depth, rin, zin, cin)
+    N = len(theta_ode_deg)
+    r = np.linspace(source_range, receiver_range, S)
+    T = np.full((N, S), np.nan)
+    Z = np.full((N, S), np.nan)
+    P = np.full((N, S), np.nan)
+    nb = np.zeros(N, np.int64)
+    ns = np.zeros(N, np.int64)
+    ok = np.zeros(N, np.int64)
+    nsteps = np.zeros(N, np.int64)
+    nfev = np.zeros(N, np.int64)
+    nseg = np.zeros(N, np.int64)
+    y0s = np.zeros((N, 3))
+    for k, th in enumerate(theta_ode_deg):
+        y0 = np.array([0, source_depth, np.sin(np.radians(th)) / c])
+        y0s[k] = y0
+        sols, full_ray, n_b, n_s = lr._shoot_ray_array(
+            y0.copy(), source_depth, source_range, receiver_range, cin, cpin, rin, zin,
+            depths, depth_ranges, bottom_angles, rtol, terminate_backwards, False)
+        if full_ray is None:
+            continue
+        out = lr._interpolate_ray(sols, r)
+        T[k], Z[k], P[k] = out[1], out[2], out[3]
+        nb[k], ns[k], ok[k] = n_b, n_s, 1
+        nsteps[k] = sum(len(s.t) - 1 for s in sols)
+        nfev[k] = sum(s.nfev for s in sols)
+        nseg[k] = len(sols)
+    return dict(r=r, T=T, z=Z, p=P, n_bott=nb, n_surf=ns, ok=ok, n_steps=nsteps, nfev=nfev,
+                n_seg=nseg, y0=y0s)
+
+
+def pack_env(arrs, prefix="env_"):
+    names = ["cin", "cpin", "rin", "zin", "depths", "depth_ranges", "bottom_angles"]
+    return {prefix + n: np.asarray(a) for n, a in zip(names, arrs)}
+
+
+def save(name, **kw):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **kw)
+    print(f"  wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+# --------------------------------------------------------------------------
+def munk_env(r_max, nr, z, bathy_depth=5000.0, flat=False):
+    r = np.linspace(0.0, r_max, nr)
+    c2d = np.outer(np.ones(nr), munk_ssp(z))
+    return DuckEnv(c2d, r, z, np.full(nr, bathy_depth), r, flat=flat)
+
+
+def g1_fixture_case():
+    """The reference's own regression case (tests/test_physics.py:310-386):
+    nz=400, nr=30, 50 km, S=50, angles [-8..8] through shoot_rays' <70 branch."""
+    env = munk_env(50e3, 30, np.linspace(0.0, 6000.0, 400))
+    angles = [-8.0, -4.0, 0.0, 4.0, 8.0]
+    rf = pr.shoot_rays(1300.0, 0.0, angles, 50e3, 50, env, n_processes=1, debug=False,
+                       flatearth=False)
+    arrs = env_arrays(env)
+    # +-1 ulp self-noise of the reference on this coarse grid
+    c0 = pr.bilinear_interp(0.0, 1300.0, arrs[2], arrs[3], arrs[0])
+    noise_z = np.zeros(len(angles))
+    noise_t = np.zeros(len(angles))
+    for k, a in enumerate(rf.thetas):
+        p0 = np.sin(np.radians(a)) / c0
+        outs = []
+        for p in (np.nextafter(p0, -1), p0, np.nextafter(p0, 1)):
+            sols, fr, _, _ = lr._shoot_ray_array(np.array([0, 1300.0, p]), 1300.0, 0.0, 50e3,
+                                                 *arrs, 1e-9, True, False)
+            outs.append(sols[-1].y[:, -1].copy())
+        outs = np.array(outs)
+        noise_t[k] = np.ptp(outs[:, 0])
+        noise_z[k] = np.ptp(outs[:, 1])
+    save("g1_fixture_case.npz", angles_user=np.array(angles), thetas=rf.thetas, rs=rf.rs,
+         ts=rf.ts, zs=rf.zs, ps=rf.ps, n_botts=rf.n_botts, n_surfs=rf.n_surfs,
+         source_depth=1300.0, source_range=0.0, receiver_range=50e3, S=50,
+         selfnoise_t=noise_t, selfnoise_z=noise_z, **pack_env(arrs))
+
+
+def g2_munk_100km():
+    """BASELINE config[0]-shaped: dz=1 m Munk, 64 angles, 100 km (S=101 to keep it small).
+    Both sign conventions of Q1 are covered by passing ODE angles +-."""
+    z = np.arange(0, 6000, 1.0)
+    env = munk_env(100e3, 100, z)
+    arrs = env_arrays(env)
+    theta = np.linspace(-20, 20, 64)
+    out = shoot_array_level(arrs, 1000.0, 0.0, 100e3, theta, 101)
+    # the table is range independent: store one row + nr (rebuilt by the test)
+    save("g2_munk_100km.npz", theta_ode=theta, source_depth=1000.0, source_range=0.0,
+         receiver_range=100e3, c_row=arrs[0][0], cp_row=arrs[1][0], rin=arrs[2], zin=arrs[3],
+         depths=arrs[4], depth_ranges=arrs[5], bottom_angles=arrs[6], **out)
+    # also the public API path for 3 of them (reference shoot_ray sign convention, Q2/Q3)
+    rays = [pr.shoot_ray(1000.0, 0.0, a, 100e3, 101, env, debug=False, flatearth=False)
+            for a in (-12.5, 3.0, 17.0)]
+    save("g2_shoot_ray_api.npz", user_angles=np.array([-12.5, 3.0, 17.0]),
+         launch_angle=np.array([r.launch_angle for r in rays]),
+         r=np.array([r.r for r in rays]), t=np.array([r.t for r in rays]),
+         z=np.array([r.z for r in rays]), p=np.array([r.p for r in rays]),
+         n_bottom=np.array([r.n_bottom for r in rays]),
+         n_surface=np.array([r.n_surface for r in rays]))
+
+
+def g3_munk_1000km():
+    """BASELINE config[1]-shaped subset: 1000 km, 16 angles incl. +-16, +-20 (many bounces),
+    S=101, with step counts and +-1 ulp self-noise of the reference end state."""
+    z = np.arange(0, 6000, 1.0)
+    env = munk_env(1000e3, 100, z)
+    arrs = env_arrays(env)
+    theta = np.array([-20.0, -16.0, -13.0, -11.0, -8.0, -5.0, -2.5, -0.3, 0.0, 1.7, 4.0, 7.5,
+                      10.0, 12.7, 16.0, 19.3])
+    out = shoot_array_level(arrs, 1000.0, 0.0, 1000e3, theta, 101)
+    c0 = pr.bilinear_interp(0.0, 1000.0, arrs[2], arrs[3], arrs[0])
+    noise = np.zeros((len(theta), 3))
+    for k, th in enumerate(theta):
+        p0 = np.sin(np.radians(th)) / c0
+        ends = []
+        for p in (np.nextafter(p0, -1), np.nextafter(p0, 1)):
+            sols, fr, _, _ = lr._shoot_ray_array(np.array([0, 1000.0, p]), 1000.0, 0.0, 1000e3,
+                                                 *arrs, 1e-9, True, False)
+            ends.append(sols[-1].y[:, -1].copy() if fr is not None else np.full(3, np.nan))
+        ends.append(np.array([out["T"][k, -1], out["z"][k, -1], out["p"][k, -1]]))
+        noise[k] = np.ptp(np.array(ends), axis=0)
+    save("g3_munk_1000km.npz", theta_ode=theta, source_depth=1000.0, source_range=0.0,
+         receiver_range=1000e3, c_row=arrs[0][0], cp_row=arrs[1][0], rin=arrs[2], zin=arrs[3],
+         depths=arrs[4], depth_ranges=arrs[5], bottom_angles=arrs[6], selfnoise_end=noise, **out)
+
+
+def g4_range_dependent():
+    """Range-dependent c(r,z) + sloping bottom of tests/test_physics.py:494-506, forward,
+    backward (mirrored, launch_rays.py:684-714) and through shoot_ray; plus a BASELINE
+    config[2]-shaped (dz=1 m, sofar depth drifting 2e-4*r, 1000 km) subset."""
+    z = np.linspace(0.0, 6000.0, 400)
+    r = np.linspace(0.0, 100e3, 80)
+    c2d = np.array([munk_ssp(z, sofar_depth=1300 + 0.01 * ri) for ri in r])
+    bathy = np.linspace(4500.0, 4900.0, len(r))
+    env = DuckEnv(c2d, r, z, bathy, r)
+    arrs = env_arrays(env)
+    theta = np.array([-15.0, -9.0, -3.0, 2.0, 8.0, 14.0, 18.0])
+    fwd = shoot_array_level(arrs, 200.0, 10e3, 90e3, theta, 81)
+    cin_m, cpin_m, rin_m, depths_m, dr_m, ba_m = lr._mirror_envi_arrays(
+        arrs[0], arrs[1], arrs[2], arrs[4], arrs[5], arrs[6])
+    arrs_m = (cin_m, cpin_m, rin_m, arrs[3], depths_m, dr_m, ba_m)
+    bwd = shoot_array_level(arrs_m, 200.0, -60e3, -10e3, theta, 80)
+    rb = pr.shoot_ray(200.0, 60e3, -15.0, 10e3, 80, env, rtol=1e-9, flatearth=False, debug=False)
+    save("g4_range_dependent.npz", theta_ode=theta,
+         **pack_env(arrs), **{"fwd_" + k: v for k, v in fwd.items()},
+         **{"bwd_" + k: v for k, v in bwd.items()},
+         api_bwd_r=rb.r, api_bwd_t=rb.t, api_bwd_z=rb.z, api_bwd_p=rb.p,
+         api_bwd_nb=rb.n_bottom, api_bwd_ns=rb.n_surface, api_bwd_launch_angle=rb.launch_angle)
+
+    # config[2]-shaped: big table is rebuilt by the test from the formula below
+    z1 = np.arange(0, 6000, 1.0)
+    r1 = np.linspace(0.0, 1000e3, 101)
+    c2 = np.array([munk_ssp(z1, sofar_depth=1300 + 2e-4 * ri) for ri in r1])
+    env2 = DuckEnv(c2, r1, z1, np.full(101, 5000.0), r1)
+    arrs2 = env_arrays(env2)
+    theta2 = np.array([-19.0, -14.0, -9.0, -4.0, 0.5, 6.0, 11.0, 15.0])
+    out2 = shoot_array_level(arrs2, 1000.0, 0.0, 1000e3, theta2, 101)
+    save("g4_config2_subset.npz", theta_ode=theta2, source_depth=1000.0,
+         sofar_slope=2e-4, nr=101, r_max=1000e3, cp_checksum=np.sum(arrs2[1]),
+         c_checksum=np.sum(arrs2[0]), **out2)
+
+
+def g5_analytic_envs():
+    """Constant-c and linear-gradient environments of tests/test_physics.py:25-51 with
+    surface+bottom bounces, steep (terminating) rays, and flat-earth tables."""
+    # constant c: 30 km, bounces
+    zc = np.linspace(0.0, 5000.0, 200)
+    rc = np.linspace(0.0, 100e3, 20)
+    envc = DuckEnv(np.full((20, 200), 1500.0), rc, zc, np.full(20, 4500.0), rc)
+    arrc = env_arrays(envc)
+    th = np.array([-15.0, -10.0, -5.0, 5.0, 10.0, 15.0, 40.0, 60.0, 80.0])
+    outc = shoot_array_level(arrc, 200.0, 0.0, 30e3, th, 60)
+    save("g5_const_c.npz", theta_ode=th, **pack_env(arrc), **outc)
+    # near-vertical rays over a short range (tests/test_physics.py:394-455 use rtol=1e-6);
+    # an initially vertical ray never fires vertical_ray (event starts at +1, Q6)
+    thv = np.array([85.0, 89.0, -89.0])
+    outv = shoot_array_level(arrc, 200.0, 0.0, 1.5e3, thv, 31, rtol=1e-6)
+    save("g5_const_c_steep.npz", theta_ode=thv, rtol=1e-6, **pack_env(arrc), **outv)
+    # linear gradient
+    zl = np.linspace(0.0, 5000.0, 500)
+    rl = np.linspace(0.0, 100e3, 50)
+    envl = DuckEnv(np.outer(np.ones(50), 1500.0 + 0.05 * zl), rl, zl, np.full(50, 4500.0), rl)
+    arrl = env_arrays(envl)
+    thl = np.array([-20.0, -12.0, 3.0, 20.0])
+    outl = shoot_array_level(arrl, 200.0, 0.0, 80e3, thl, 400)
+    save("g5_linear_gradient.npz", theta_ode=thl, **pack_env(arrl),
+         **{k: (v[:, ::4] if v.ndim == 2 and v.shape[1] == 400 else v) for k, v in outl.items()
+            if k != "r"}, r=outl["r"][::4])
+    # flat-earth tables (non-uniform depth grid) + default sloping bathymetry (Q11), 100 km
+    zf = np.arange(0, 6000, 4.0)
+    rf = np.linspace(0.0, 100e3, 100)
+    envf = DuckEnv(np.outer(np.ones(100), munk_ssp(zf)), rf, zf, np.linspace(4500, 4900, 100), rf,
+                   lat=35.0, flat=True)
+    arrf = env_arrays(envf, flatearth=True)
+    thf = np.array([-14.0, -6.0, 0.0, 5.0, 12.0])
+    outf = shoot_array_level(arrf, 800.0, 0.0, 100e3, thf, 101)
+    save("g5_flatearth.npz", theta_ode=thf, **pack_env(arrf), **outf)
+
+
+def g6_eigenrays():
+    """Eigenray search (the reference has no tests for it): fan end depths, brackets, and the
+    per-bracket result of the reference's _find_single_eigenray (eigenrays.py:206-268).
+
+    The search is only self-consistent for fans from shoot_rays' >=70-ray branch (Q1: there
+    RayFan.thetas = user angle and the ODE angle is -user, the same as shoot_ray).  That
+    branch runs a spawn pool (workers cannot see the stand-in modules), so the fan is
+    assembled here exactly as launch_rays.py:140-186 does it, from the same per-ray call
+    (_shoot_ray_array + _interpolate_ray + pr.Ray) the pool workers make."""
+    z = np.arange(0, 6000, 1.0)
+    env = munk_env(100e3, 100, z)
+    arrs = env_arrays(env)
+    angles = np.linspace(-12, 12, 80)
+    la = -angles                                                   # launch_rays.py:67
+    out = shoot_array_level(arrs, 1000.0, 0.0, 100e3, la, 21)
+    rays = []
+    for k in range(len(angles)):
+        ray = pr.Ray(out["r"], np.stack([out["T"][k], out["z"][k], out["p"][k]]),
+                     out["n_bott"][k], out["n_surf"][k], source_depth=1000.0)
+        ray.launch_angle = -la[k]                                  # launch_rays.py:180
+        rays.append(ray)
+    fan = pr.RayFan(rays)
+    rd = 1000.0
+    depth_sign = np.sign(fan.zs[:, -1] + rd)                       # eigenrays.py:65-69
+    starts = np.where(np.diff(depth_sign))[0]
+    res = []
+    for k, s in enumerate(starts):
+        z1, z2 = fan.zs[s, -1], fan.zs[s + 1, -1]
+        t1, t2 = fan.thetas[s], fan.thetas[s + 1]
+        rft = t1 - (z1 + rd) * (t2 - t1) / (z2 - z1)               # eigenrays.py:118-120
+        ray = er._find_single_eigenray((k, z1, z2, t1, t2, rft, rd, 1000.0, 0.0, 100e3, 21, env,
+                                        1, 20, dict(debug=False, flatearth=False)))
+        if ray is None:
+            res.append([np.nan] * 6)
+        else:
+            res.append([ray.launch_angle, ray.t[-1], ray.z[-1], ray.p[-1], ray.n_bottom,
+                        ray.n_surface])
+    save("g6_eigenrays.npz", fan_angles_user=angles, fan_thetas=fan.thetas, fan_z_end=fan.zs[:, -1],
+         fan_t_end=fan.ts[:, -1], receiver_depth=rd, bracket_starts=starts,
+         eigen=np.array(res, dtype=float), source_depth=1000.0, receiver_range=100e3, S=21)
+
+
+def g7_unit_vectors():
+    """Unit vectors for a1-a8 (integration_processes.py): random points inside and outside
+    the grid (Q4 extrapolation), |p c|>1 -> NaN angle (Q7), clamp (Q8)."""
+    rng = np.random.default_rng(0)
+    z = np.linspace(0.0, 6000.0, 61) ** 1.0
+    z[1:-1] += rng.uniform(-20, 20, 59)  # non-uniform depth grid
+    r = np.sort(rng.uniform(0, 100e3, 12))
+    r[0], r[-1] = 0.0, 100e3
+    cin = np.array([munk_ssp(z, sofar_depth=1300 + 0.002 * ri) for ri in r])
+    cpin = np.gradient(cin, z, axis=1, edge_order=1)
+    dr = np.linspace(0, 100e3, 7)
+    depths = np.array([4500.0, 4700.0, 4300.0, 4800.0, 4900.0, 4650.0, 4500.0])
+    M = 400
+    xs = rng.uniform(-5e3, 105e3, M)
+    zs = rng.uniform(-200, 6200, M)
+    # exact-node queries (searchsorted side='left' semantics)
+    xs[:12] = r
+    zs[12:73] = z
+    ps = rng.uniform(-7.2e-4, 7.2e-4, M)
+    ys = np.stack([rng.uniform(0, 100, M), zs, ps], 1)
+    bil = np.array([pr.bilinear_interp(x, zz, r, z, cin) for x, zz in zip(xs, zs)])
+    lin = np.array([pr.linear_interp(x, dr, depths) for x in xs])
+    der = np.array([pr.derivsrd(x, y, cin, cpin, r, z, depths, dr) for x, y in zip(xs, ys)])
+    with np.errstate(invalid="ignore"):
+        ang = np.array([pr.ray_angle(x, y, cin, r, z) for x, y in zip(xs, ys)])
+        ev = np.array([[f(x, y, cin, cpin, r, z, depths, dr) for f in
+                        (pr.surface_bounce, pr.bottom_bounce, pr.vertical_ray,
+                         pr.ray_bounding_box_event)] for x, y in zip(xs, ys)])
+    save("g7_unit_vectors.npz", cin=cin, cpin=cpin, rin=r, zin=z, depths=depths, depth_ranges=dr,
+         xs=xs, ys=ys, bilinear=bil, linear=lin, derivs=der, angle=ang, events=ev)
+
+
+def g8_timing():
+    """Reference (un-jitted) CPU cost on config[0] for BASELINE bookkeeping."""
+    z = np.arange(0, 6000, 1.0)
+    env = munk_env(100e3, 100, z)
+    arrs = env_arrays(env)
+    theta = np.linspace(-20, 20, 64)
+    t0 = time.time()
+    out = shoot_array_level(arrs, 1000.0, 0.0, 100e3, theta, 1001)
+    dt = time.time() - t0
+    print(f"  config0 reference (un-jitted, 1 core): {dt:.2f} s, "
+          f"{out['n_steps'].sum()} ray-steps -> {out['n_steps'].sum() / dt:.0f} ray-steps/s")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    table = dict(g1=g1_fixture_case, g2=g2_munk_100km, g3=g3_munk_1000km, g4=g4_range_dependent,
+                 g5=g5_analytic_envs, g6=g6_eigenrays, g7=g7_unit_vectors, g8=g8_timing)
+    for w in which:
+        print(w)
+        table[w]()
