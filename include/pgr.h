@@ -1,0 +1,111 @@
+/*
+ * pgr.h -- C ABI of the MI355X-native pygenray hot path (libpgr_hip.so).
+ *
+ * pygenray has no FFI/plugin interface; the seam this library slots into is the
+ * array-level contract pygenray itself uses to cross its process boundary
+ * (REF = /root/reference/src/pygenray):
+ *
+ *   - the 7 environment arrays  cin, cpin, rin, zin, depths, depth_ranges,
+ *     bottom_angle                      REF/multi_processing.py:37-45,90
+ *   - per-ray y0 = [T0, z0, p0] + scalars, i.e. the argument list of
+ *     _shoot_single_ray_process / _shoot_ray_array
+ *                                       REF/launch_rays.py:487-497, 325-340
+ *   - per-ray result [r; T; z; p] on linspace(source_range, receiver_range,
+ *     num_range_save) + n_bottom, n_surface, or "None" for a dropped ray
+ *                                       REF/launch_rays.py:561-576, 745-784
+ *
+ * Everything is plain pointers and sizes: no torch / HIP types in signatures
+ * (a HIP stream is passed as void*).  All floating point is IEEE binary64.
+ * Values are in the ODE convention (depth positive down); the caller applies
+ * pygenray's storage sign flip z -> -z, p -> -p (REF/ray_objects.py:51-52).
+ *
+ * Return value of every int function: 0 = success, <0 = error (see
+ * pgr_last_error()).  No exception or signal crosses this boundary; per-ray
+ * failures are reported in status[] (pygenray swallows them and drops the
+ * ray, REF/launch_rays.py:578-581).
+ */
+#ifndef PGR_H
+#define PGR_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* per-ray status codes (status[k]) */
+#define PGR_RAY_OK 0             /* reached receiver_range */
+#define PGR_RAY_VERTICAL 1       /* vertical_ray event      REF/launch_rays.py:443-448 */
+#define PGR_RAY_BBOX 2           /* left the c(r,z) table    REF/launch_rays.py:451-456 */
+#define PGR_RAY_BACKWARD 3       /* |theta_bounce| > 90      REF/launch_rays.py:474-477 */
+#define PGR_RAY_STEP_TOO_SMALL 4 /* solve_ivp status -1      REF/launch_rays.py:427-430 */
+#define PGR_RAY_MAX_STEPS 5      /* guard: max_steps accepted steps exceeded (no reference counterpart) */
+#define PGR_RAY_BETA_RANGE 6     /* bottom-angle interp1d out of bounds (ValueError) REF/launch_rays.py:469 */
+#define PGR_RAY_EVENT_ERROR 7    /* event root not bracketed (brentq ValueError) */
+
+/* flags for pgr_shoot_fan* */
+#define PGR_TERMINATE_BACKWARDS 1u /* REF/launch_rays.py:19,474 (default True) */
+#define PGR_SAMPLE_MAJOR 2u        /* T/z/p laid out [S][N] instead of [N][S] */
+
+typedef struct pgr_env pgr_env; /* opaque: environment tables resident in HBM */
+
+/* Number of visible HIP devices (<0 on error). */
+int pgr_device_count(void);
+
+/* Upload one environment (the 7-array contract, REF/multi_processing.py:37-45) to
+ * `device`.  Replaces _init_shared_memory/_unpack_shared_memory: one H2D copy instead of
+ * 7 POSIX shm blocks.  cin/cpin are [nr][nz] C-contiguous (range-major), bottom_angles in
+ * degrees.  Coordinates must be non-decreasing (REF/launch_rays.py:79-90) and nb >= 4
+ * (cubic interp1d, REF/launch_rays.py:397-399).  Host buffers stay owned by the caller. */
+int pgr_env_create(pgr_env** env, int device, const double* cin, const double* cpin,
+                   const double* rin, const double* zin, int64_t nr, int64_t nz,
+                   const double* depths, const double* depth_ranges, const double* bottom_angles,
+                   int64_t nb);
+void pgr_env_destroy(pgr_env* env);
+
+/* Properties the kernel selection depends on (for tests / diagnostics):
+ * what = 0: tables range independent (all rows bitwise equal) ; 1: zin exactly uniform ;
+ *        2: rin exactly uniform ; 3: LDS-resident table path selected ; 4: device index. */
+int pgr_env_query(const pgr_env* env, int what);
+
+/* Shoot N rays: batched _shoot_ray_array + _interpolate_ray (REF/launch_rays.py:325-484,
+ * 745-784) with SciPy's RK45 defaults (REF/launch_rays.py:670-679: rtol given, atol 1e-6,
+ * dense output, 4 terminal events).
+ *
+ *   y0[N][3]      initial [T, z, p]   (REF/launch_rays.py:140-144)
+ *   r_save[S]     np.linspace(source_range, receiver_range, S), computed by the caller
+ *   T,z,p         [N][S] (or [S][N] with PGR_SAMPLE_MAJOR); may all be NULL = end state only.
+ *                 Rays with status != 0 are filled with NaN.
+ *   end_state     [N][3] exact final [T,z,p] (= last column), may be NULL
+ *   n_bott,n_surf [N] bounce counts ; status [N] ; n_steps [N] accepted RK45 steps ;
+ *   n_rej [N] rejected attempts (n_steps/n_rej may be NULL)
+ *
+ * pgr_shoot_fan takes HOST pointers (copies in/out, synchronous).
+ * pgr_shoot_fan_device takes DEVICE pointers on env's device, enqueues on `stream`
+ * (hipStream_t as void*, NULL = default stream) and returns without synchronising. */
+int pgr_shoot_fan(pgr_env* env, const double* y0, int64_t N, double source_range,
+                  double receiver_range, const double* r_save, int32_t S, double rtol, double atol,
+                  uint32_t flags, int64_t max_steps, double* T, double* z, double* p,
+                  double* end_state, int32_t* n_bott, int32_t* n_surf, int32_t* status,
+                  int32_t* n_steps, int32_t* n_rej);
+int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, double source_range,
+                         double receiver_range, const double* r_save, int32_t S, double rtol,
+                         double atol, uint32_t flags, int64_t max_steps, double* T, double* z,
+                         double* p, double* end_state, int32_t* n_bott, int32_t* n_surf,
+                         int32_t* status, int32_t* n_steps, int32_t* n_rej, void* stream);
+
+/* Tuning knob: waves (of 64 rays) per workgroup; 0 = automatic. */
+int pgr_set_waves_per_block(int waves);
+
+/* Unit-level device entry points (for parity tests of a1-a8, REF/integration_processes.py):
+ * evaluate on the GPU, for M query points (x[k], y[k][3]) given as HOST arrays:
+ *   out[k][0..2] = derivsrd ; out[k][3] = bilinear c ; out[k][4] = ray angle (deg) ;
+ *   out[k][5..8] = surface, bottom, vertical, bbox event values (+-1) ; out[k][9] = bathymetry
+ *   linear_interp at x. */
+int pgr_eval_points(pgr_env* env, const double* x, const double* y, int64_t M, double* out10);
+
+/* Message for the last error on the calling thread. */
+const char* pgr_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGR_H */

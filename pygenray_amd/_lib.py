@@ -1,0 +1,194 @@
+"""ctypes binding of the C ABI in include/pgr.h (libpgr_hip.so).
+
+The product path is HIP only: if the library is missing or cannot be loaded this module
+raises -- there is no CPU fallback (the CPU oracle under oracle/ is test infrastructure and
+is never imported from here).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libpgr_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-ffp-contract=off"]
+
+PGR_TERMINATE_BACKWARDS = 1
+PGR_SAMPLE_MAJOR = 2
+
+RAY_STATUS = {0: "ok", 1: "vertical", 2: "bbox", 3: "backward", 4: "step_too_small",
+              5: "max_steps", 6: "bottom_angle_range", 7: "event_error"}
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int32)
+_i64 = ctypes.c_int64
+_vp = ctypes.c_void_p
+
+_lib = None
+
+
+class PgrError(RuntimeError):
+    pass
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/pgr_hip.hip for gfx950 (cross-compiles without a GPU)."""
+    src = os.path.join(CSRC, "pgr_hip.hip")
+    hdr = os.path.join(_HERE, "..", "include", "pgr.h")
+    if not force and os.path.exists(LIB_PATH):
+        newest = max(os.path.getmtime(src), os.path.getmtime(hdr))
+        if os.path.getmtime(LIB_PATH) >= newest:
+            return LIB_PATH
+    cmd = [HIPCC] + HIPCC_FLAGS + ["-o", LIB_PATH, src]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def load():
+    """Load libpgr_hip.so; raise loudly if it is absent (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PgrError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+            "pygenray_amd has no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    L.pgr_last_error.restype = ctypes.c_char_p
+    L.pgr_device_count.restype = ctypes.c_int
+    L.pgr_env_create.restype = ctypes.c_int
+    L.pgr_env_create.argtypes = [ctypes.POINTER(_vp), ctypes.c_int, _dp, _dp, _dp, _dp, _i64, _i64,
+                                 _dp, _dp, _dp, _i64]
+    L.pgr_env_destroy.restype = None
+    L.pgr_env_destroy.argtypes = [_vp]
+    L.pgr_env_query.restype = ctypes.c_int
+    L.pgr_env_query.argtypes = [_vp, ctypes.c_int]
+    fan_common = [_vp, _vp, _i64, ctypes.c_double, ctypes.c_double, _vp, ctypes.c_int32,
+                  ctypes.c_double, ctypes.c_double, ctypes.c_uint32, _i64, _vp, _vp, _vp, _vp, _vp,
+                  _vp, _vp, _vp, _vp]
+    L.pgr_shoot_fan.restype = ctypes.c_int
+    L.pgr_shoot_fan.argtypes = fan_common
+    L.pgr_shoot_fan_device.restype = ctypes.c_int
+    L.pgr_shoot_fan_device.argtypes = fan_common + [_vp]
+    L.pgr_set_waves_per_block.restype = ctypes.c_int
+    L.pgr_set_waves_per_block.argtypes = [ctypes.c_int]
+    L.pgr_eval_points.restype = ctypes.c_int
+    L.pgr_eval_points.argtypes = [_vp, _dp, _dp, _i64, _dp]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise PgrError(load().pgr_last_error().decode())
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _vptr(a):
+    return None if a is None else ctypes.c_void_p(a.ctypes.data)
+
+
+class EnvHandle:
+    """Owns one pgr_env (environment tables resident in HBM on `device`)."""
+
+    def __init__(self, cin, cpin, rin, zin, depths, depth_ranges, bottom_angles, device=0):
+        L = load()
+        cin, cpin, rin, zin = _c(cin), _c(cpin), _c(rin), _c(zin)
+        depths, depth_ranges, bottom_angles = _c(depths), _c(depth_ranges), _c(bottom_angles)
+        if cin.ndim != 2 or cin.shape != cpin.shape or cin.shape != (len(rin), len(zin)):
+            raise ValueError("cin/cpin must have shape (len(rin), len(zin))")
+        if not (len(depths) == len(depth_ranges) == len(bottom_angles)):
+            raise ValueError("depths, depth_ranges and bottom_angles must have equal length")
+        h = _vp()
+        check(L.pgr_env_create(ctypes.byref(h), int(device), _p(cin), _p(cpin), _p(rin), _p(zin),
+                               len(rin), len(zin), _p(depths), _p(depth_ranges), _p(bottom_angles),
+                               len(depths)))
+        self._h = h
+        self.device = int(device)
+        self.shape = cin.shape
+
+    def query(self, what):
+        return load().pgr_env_query(self._h, int(what))
+
+    @property
+    def range_independent(self):
+        return bool(self.query(0))
+
+    @property
+    def lds_path(self):
+        return bool(self.query(3))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().pgr_env_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host-pointer entry (NumPy in / NumPy out) ----
+    def shoot_fan(self, y0, source_range, receiver_range, num_range_save, rtol=1e-9, atol=1e-6,
+                  terminate_backwards=True, max_steps=1_000_000, save=True, sample_major=False):
+        L = load()
+        y0 = _c(y0).reshape(-1, 3)
+        N, S = len(y0), int(num_range_save)
+        r = np.linspace(source_range, receiver_range, S)
+        flags = (PGR_TERMINATE_BACKWARDS if terminate_backwards else 0) | \
+            (PGR_SAMPLE_MAJOR if sample_major else 0)
+        if save:
+            shape = (S, N) if sample_major else (N, S)
+            T = np.empty(shape); Z = np.empty(shape); P = np.empty(shape)
+        else:
+            T = Z = P = None
+        end = np.empty((N, 3))
+        nb = np.zeros(N, np.int32); ns = np.zeros(N, np.int32); st = np.zeros(N, np.int32)
+        nsteps = np.zeros(N, np.int32); nrej = np.zeros(N, np.int32)
+        check(L.pgr_shoot_fan(self._h, _vptr(y0), N, float(source_range), float(receiver_range),
+                              _vptr(r), S, float(rtol), float(atol), flags, int(max_steps),
+                              _vptr(T), _vptr(Z), _vptr(P), _vptr(end), _vptr(nb), _vptr(ns),
+                              _vptr(st), _vptr(nsteps), _vptr(nrej)))
+        return dict(r=r, T=T, z=Z, p=P, end=end, n_bott=nb, n_surf=ns, status=st, n_steps=nsteps,
+                    n_rej=nrej)
+
+    # ---- device-pointer entry (integers are raw device addresses, e.g. tensor.data_ptr()) ----
+    def shoot_fan_device(self, y0_ptr, N, source_range, receiver_range, r_ptr, S, rtol, atol, flags,
+                         max_steps, T_ptr, Z_ptr, P_ptr, end_ptr, nb_ptr, ns_ptr, st_ptr,
+                         nsteps_ptr, nrej_ptr, stream=0):
+        L = load()
+        v = lambda q: ctypes.c_void_p(q) if q else None  # noqa: E731
+        check(L.pgr_shoot_fan_device(self._h, v(y0_ptr), int(N), float(source_range),
+                                     float(receiver_range), v(r_ptr), int(S), float(rtol),
+                                     float(atol), int(flags), int(max_steps), v(T_ptr), v(Z_ptr),
+                                     v(P_ptr), v(end_ptr), v(nb_ptr), v(ns_ptr), v(st_ptr),
+                                     v(nsteps_ptr), v(nrej_ptr), v(stream)))
+
+    def eval_points(self, x, y):
+        x = _c(x); y = _c(y).reshape(-1, 3)
+        out = np.empty((len(x), 10))
+        check(load().pgr_eval_points(self._h, _p(x), _p(y), len(x), _p(out)))
+        return out
+
+
+def device_count():
+    return load().pgr_device_count()
+
+
+def set_waves_per_block(w):
+    check(load().pgr_set_waves_per_block(int(w)))

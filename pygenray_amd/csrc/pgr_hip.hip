@@ -1,0 +1,968 @@
+// pgr_hip.hip -- MI355X (gfx950) ray-fan integrator behind the C ABI of include/pgr.h.
+//
+// One ray per lane (wave64).  Every lane runs SciPy's adaptive Dormand-Prince 5(4)
+// controller on the ray equations y = [T, z, p] over range x with the reference's
+// bilinear c / dc/dz tables, +-1 step-function events located by brentq-style
+// bisection on the quartic dense output, reflection at surface / bottom and the
+// reference's nearest-index re-sampling -- restating, on the device,
+//   REF/integration_processes.py:26-334   (derivsrd, bilinear/linear interp, events)
+//   REF/launch_rays.py:325-484, 593-681    (_shoot_ray_array, _shoot_ray_segment)
+//   REF/launch_rays.py:745-784             (_interpolate_ray)
+//   SCIPY/rk.py:14-180,377-404,552-574 ; SCIPY/common.py:63-134 ; SCIPY/ivp.py:28-156,654-726
+// (REF = /root/reference/src/pygenray, SCIPY = scipy/integrate/_ivp of SciPy 1.15.3).
+//
+// Layout: the c and dc/dz tables are interleaved node-wise as double2 {c, cp} so one
+// 16-byte access fetches both values of a node; for range-independent tables the single
+// depth profile (nz x 16 B, 96 KB at nz = 6000) is staged into LDS once per workgroup.
+// State (x, y, f, h, K1..K7) lives in VGPRs.  No MFMA: there is no contraction here.
+//
+// Arithmetic is written in the reference's operation order and compiled with
+// -ffp-contract=off; IEEE fp64 divide / sqrt are correctly rounded on gfx950, so the
+// only non-bit-identical operations w.r.t. the CPU oracle are pow / asin / sin (libm vs ocml).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <float.h>
+#include <string>
+#include <vector>
+#include <mutex>
+
+#include "../../include/pgr.h"
+
+// ------------------------------------------------------------------------------------
+// device-side environment description
+// ------------------------------------------------------------------------------------
+struct EnvDev {
+    const double2* tab;  // [nr][nz] {c, cp}
+    const double* rin;   // [nr]
+    const double* zin;   // [nz]
+    const double* depths;        // [nb]
+    const double* depth_ranges;  // [nb]
+    const double* pp;            // [nb-1][4] not-a-knot cubic of bottom_angles
+    int nr, nz, nb;
+    int row_stride;  // nz, or 0 when the table is range independent (one stored row)
+    int z_uniform, r_uniform, b_uniform;  // grid[j] == g0 + j*dg bitwise (host verified)
+    double z0, dz, inv_dz;
+    double r0, dr, inv_dr;
+    double b0, db, inv_db;
+    double zlo_tol, zhi_tol, rlo_tol, rhi_tol;  // bbox bounds -+ 1e-6 (REF/integration_processes.py:295-302)
+};
+
+struct FanArgs {
+    const double* y0;      // [N][3]
+    const double* r_save;  // [S]
+    double* T;
+    double* Z;
+    double* P;             // may be null
+    double* end_state;     // [N][3] may be null
+    int32_t* n_bott;
+    int32_t* n_surf;
+    int32_t* status;
+    int32_t* n_steps;
+    int32_t* n_rej;
+    int64_t N;
+    int64_t stride_ray, stride_smp;  // element strides of T/Z/P
+    int32_t S;
+    double x0, x1, rtol, atol;
+    double inv_dsave;  // (S-1)/(x1-x0) guess for nearest-sample index
+    int64_t max_steps;
+    uint32_t flags;
+};
+
+#define RUNNING (-1)
+
+// ------------------------------------------------------------------------------------
+// grid cell lookup: np.searchsorted(grid, q) - 1 clamped to [0, n-2]
+// (REF/integration_processes.py:152-157).  side='left': grid[j] < q <= grid[j+1].
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ int cell_uniform(double q, double g0, double dg, double inv_dg, int n)
+{
+    double t = (q - g0) * inv_dg;
+    t = fmin(fmax(t, -1.0), (double)n);  // NaN -> -1
+    int j = (int)floor(t);
+    double gj = g0 + (double)j * dg;
+    if (gj >= q) {
+        j -= 1;
+    } else {
+        double gj1 = g0 + (double)(j + 1) * dg;
+        if (gj1 < q) j += 1;
+    }
+    return min(max(j, 0), n - 2);
+}
+
+__device__ __forceinline__ int cell_search(double q, const double* __restrict__ g, int n)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (g[mid] < q) lo = mid + 1; else hi = mid;
+    }
+    return min(max(lo - 1, 0), n - 2);
+}
+
+// ------------------------------------------------------------------------------------
+// per-kernel context: where table nodes come from
+// ------------------------------------------------------------------------------------
+template <bool LDS_TAB>
+struct Ctx {
+    const EnvDev& e;
+    const double2* lds;  // LDS copy of the (single) depth profile when LDS_TAB
+    __device__ __forceinline__ Ctx(const EnvDev& e_, const double2* l) : e(e_), lds(l) {}
+
+    __device__ __forceinline__ int cell_z(double z, double& zj, double& zj1) const
+    {
+        int j;
+        if (e.z_uniform) {
+            j = cell_uniform(z, e.z0, e.dz, e.inv_dz, e.nz);
+            zj = e.z0 + (double)j * e.dz;
+            zj1 = e.z0 + (double)(j + 1) * e.dz;
+        } else {
+            j = cell_search(z, e.zin, e.nz);
+            zj = e.zin[j];
+            zj1 = e.zin[j + 1];
+        }
+        return j;
+    }
+    __device__ __forceinline__ int cell_r(double x, double& ri, double& ri1) const
+    {
+        int i;
+        if (e.r_uniform) {
+            i = cell_uniform(x, e.r0, e.dr, e.inv_dr, e.nr);
+            ri = e.r0 + (double)i * e.dr;
+            ri1 = e.r0 + (double)(i + 1) * e.dr;
+        } else {
+            i = cell_search(x, e.rin, e.nr);
+            ri = e.rin[i];
+            ri1 = e.rin[i + 1];
+        }
+        return i;
+    }
+
+    // bilinear c and dc/dz at (x, z): REF/integration_processes.py:101-174, both tables at once
+    __device__ __forceinline__ void lookup(double x, double z, double& c, double& cp) const
+    {
+        double ri, ri1, zj, zj1;
+        int i = cell_r(x, ri, ri1);
+        int j = cell_z(z, zj, zj1);
+        double wx = (x - ri) / (ri1 - ri);
+        double wy = (z - zj) / (zj1 - zj);
+        double2 v00, v01, v10, v11;
+        if (LDS_TAB) {
+            v00 = lds[j];
+            v01 = lds[j + 1];
+            v10 = v00;  // range independent: rows are bitwise identical
+            v11 = v01;
+        } else {
+            const double2* row = e.tab + (size_t)i * e.row_stride + j;
+            v00 = row[0];
+            v01 = row[1];
+            v10 = row[e.row_stride];
+            v11 = row[e.row_stride + 1];
+        }
+        double a = (1 - wx) * (1 - wy), b = wx * (1 - wy), cc = (1 - wx) * wy, d = wx * wy;
+        c = a * v00.x + b * v10.x + cc * v01.x + d * v11.x;
+        cp = a * v00.y + b * v10.y + cc * v01.y + d * v11.y;
+    }
+
+    // bathymetry under the ray: linear_interp, REF/integration_processes.py:177-235
+    __device__ __forceinline__ double bathy(double x) const
+    {
+        int i;
+        double xi, xi1;
+        if (e.b_uniform) {
+            i = cell_uniform(x, e.b0, e.db, e.inv_db, e.nb);
+            xi = e.b0 + (double)i * e.db;
+            xi1 = e.b0 + (double)(i + 1) * e.db;
+        } else {
+            i = cell_search(x, e.depth_ranges, e.nb);
+            xi = e.depth_ranges[i];
+            xi1 = e.depth_ranges[i + 1];
+        }
+        double w = (x - xi) / (xi1 - xi);
+        return (1 - w) * e.depths[i] + w * e.depths[i + 1];
+    }
+
+    // derivsrd, REF/integration_processes.py:26-98 (clamp: Q8)
+    __device__ __forceinline__ void rhs(double x, double z, double pz, double& d0, double& d1,
+                                        double& d2, double& c) const
+    {
+        double cp;
+        lookup(x, z, c, cp);
+        double arg = 1.0 - (c * c) * (pz * pz);
+        if (arg <= 0.0) arg = 1e-30;
+        double fact = 1 / sqrt(arg);
+        d0 = fact / c;
+        d1 = c * pz * fact;
+        d2 = -fact * cp / (c * c);
+    }
+
+    // the four +-1 events (REF/integration_processes.py:238-303) as a bit mask, bit k = event
+    // k is +1.  theta = degrees(arcsin(p c)): theta < 0 <=> -1 <= pc < 0 (NaN when |pc| > 1, Q7).
+    __device__ __forceinline__ unsigned events(double x, double z, double pz, double c) const
+    {
+        double pc = pz * c;
+        unsigned g = 0;
+        if ((z < 0) && (pc < 0) && (pc >= -1.0)) g |= 1u;
+        if ((pc > 0) && (pc <= 1.0)) {
+            if (z > bathy(x)) g |= 2u;
+        }
+        if (fabs(pc) > 0.9999999998 && fabs(pc) <= 1.0) {
+            double th = asin(pc) * (180.0 / M_PI);
+            if (fabs(th) > (90 - 1e-3)) g |= 4u;
+        }
+        if ((z > e.zhi_tol) | (z < e.zlo_tol) | (x < e.rlo_tol) | (x > e.rhi_tol)) g |= 8u;
+        return g;
+    }
+};
+
+// ------------------------------------------------------------------------------------
+// Dormand-Prince coefficients, SCIPY/rk.py:377-404
+// ------------------------------------------------------------------------------------
+#define A21 (1.0 / 5)
+#define A31 (3.0 / 40)
+#define A32 (9.0 / 40)
+#define A41 (44.0 / 45)
+#define A42 (-56.0 / 15)
+#define A43 (32.0 / 9)
+#define A51 (19372.0 / 6561)
+#define A52 (-25360.0 / 2187)
+#define A53 (64448.0 / 6561)
+#define A54 (-212.0 / 729)
+#define A61 (9017.0 / 3168)
+#define A62 (-355.0 / 33)
+#define A63 (46732.0 / 5247)
+#define A64 (49.0 / 176)
+#define A65 (-5103.0 / 18656)
+#define B1 (35.0 / 384)
+#define B3 (500.0 / 1113)
+#define B4 (125.0 / 192)
+#define B5 (-2187.0 / 6784)
+#define B6 (11.0 / 84)
+#define E1 (-71.0 / 57600)
+#define E3 (71.0 / 16695)
+#define E4 (-71.0 / 1920)
+#define E5 (17253.0 / 339200)
+#define E6 (-22.0 / 525)
+#define E7 (1.0 / 40)
+#define C2 (1.0 / 5)
+#define C3 (3.0 / 10)
+#define C4 (4.0 / 5)
+#define C5 (8.0 / 9)
+
+__device__ __forceinline__ double rms3(double a, double b, double c)
+{
+    // np.linalg.norm(x) / x.size ** 0.5, SCIPY/common.py:63-65
+    return sqrt(a * a + b * b + c * c) / 1.7320508075688772;
+}
+
+// quartic dense output of one accepted step: Q = K.T @ P (SCIPY/rk.py:178-180, 393-404)
+struct Dense {
+    double t_old, h;
+    double y0, y1, y2;
+    double q[3][4];
+    __device__ __forceinline__ void eval(double t, double& o0, double& o1, double& o2) const
+    {
+        // SCIPY/rk.py:560-574: x = (t - t_old)/h ; p = cumprod ; y = h * (Q @ p) + y_old
+        double x = (t - t_old) / h;
+        double p1 = x, p2 = p1 * x, p3 = p2 * x, p4 = p3 * x;
+        o0 = h * (q[0][0] * p1 + q[0][1] * p2 + q[0][2] * p3 + q[0][3] * p4) + y0;
+        o1 = h * (q[1][0] * p1 + q[1][1] * p2 + q[1][2] * p3 + q[1][3] * p4) + y1;
+        o2 = h * (q[2][0] * p1 + q[2][1] * p2 + q[2][2] * p3 + q[2][3] * p4) + y2;
+    }
+};
+
+#define PQ(k1, k3, k4, k5, k6, k7, j)                                                   \
+    ((k1) * P1##j + (k3) * P3##j + (k4) * P4##j + (k5) * P5##j + (k6) * P6##j + (k7) * P7##j)
+// RK45.P rows (row 2 is all zero), columns 0..3
+#define P10 1.0
+#define P11 (-8048581381.0 / 2820520608)
+#define P12 (8663915743.0 / 2820520608)
+#define P13 (-12715105075.0 / 11282082432)
+#define P30 0.0
+#define P31 (131558114200.0 / 32700410799)
+#define P32 (-68118460800.0 / 10900136933)
+#define P33 (87487479700.0 / 32700410799)
+#define P40 0.0
+#define P41 (-1754552775.0 / 470086768)
+#define P42 (14199869525.0 / 1410260304)
+#define P43 (-10690763975.0 / 1880347072)
+#define P50 0.0
+#define P51 (127303824393.0 / 49829197408)
+#define P52 (-318862633887.0 / 49829197408)
+#define P53 (701980252875.0 / 199316789632)
+#define P60 0.0
+#define P61 (-282668133.0 / 205662961)
+#define P62 (2019193451.0 / 616988883)
+#define P63 (-1453857185.0 / 822651844)
+#define P70 0.0
+#define P71 (40617522.0 / 29380423)
+#define P72 (-110615467.0 / 29380423)
+#define P73 (69997945.0 / 29380423)
+
+// np.argmin(np.abs(range_save - t)) (first minimum), REF/launch_rays.py:766-767
+__device__ __forceinline__ int nearest_sample(const double* __restrict__ r, int S, double x0,
+                                              double inv_ds, double t)
+{
+    double g = (t - x0) * inv_ds;
+    g = fmin(fmax(g, 0.0), (double)(S - 1));
+    int j = (int)rint(g);
+    int best = max(j - 1, 0);
+    double bd = fabs(r[best] - t);
+    for (int k = best + 1; k <= min(j + 1, S - 1); k++) {
+        double d = fabs(r[k] - t);
+        if (d < bd) { bd = d; best = k; }
+    }
+    return best;
+}
+
+// ------------------------------------------------------------------------------------
+// the fan kernel
+// ------------------------------------------------------------------------------------
+template <bool LDS_TAB>
+__global__ void __launch_bounds__(512)
+pgr_fan_kernel(EnvDev env, FanArgs a)
+{
+    extern __shared__ double2 lds_tab[];
+    if (LDS_TAB) {
+        // stage the single depth profile {c, cp}[nz] into LDS (coalesced 16 B per lane)
+        for (int j = threadIdx.x; j < env.nz; j += blockDim.x) lds_tab[j] = env.tab[j];
+        __syncthreads();
+    }
+    const Ctx<LDS_TAB> C(env, lds_tab);
+    const int64_t ray = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = ray < a.N;
+    const double SAFETY = 0.9, MIN_FACTOR = 0.2, MAX_FACTOR = 10;
+    const double rtol = a.rtol, atol = a.atol, t_bound = a.x1;
+    const int S = a.S;
+    const bool save = (a.T != nullptr);
+
+    double t = a.x0, y0 = 0, y1 = 0, y2 = 0;
+    if (valid) {
+        y0 = a.y0[3 * ray + 0];
+        y1 = a.y0[3 * ray + 1];
+        y2 = a.y0[3 * ray + 2];
+    }
+    double f0 = 0, f1 = 0, f2 = 0, h_abs = 0;
+    unsigned g = 0;
+    int status = valid ? RUNNING : PGR_RAY_OK;
+    bool need_init = true, rejected = false;
+    int nb = 0, ns = 0, n_steps = 0, n_rej = 0;
+    int jnext = 0;
+    double rnext = 0;
+    double* Tp = save ? a.T + ray * a.stride_ray : nullptr;
+    double* Zp = save ? a.Z + ray * a.stride_ray : nullptr;
+    double* Pp = save ? a.P + ray * a.stride_ray : nullptr;
+
+    while (__any(status == RUNNING)) {
+        if (status == RUNNING) {
+            if (need_init) {
+                // ---- fresh solve_ivp: RK45.__init__ (SCIPY/rk.py:84-104) ----
+                double c;
+                C.rhs(t, y1, y2, f0, f1, f2, c);
+                // select_initial_step, SCIPY/common.py:68-134 (order 4, direction +1, max_step inf)
+                double interval = fabs(t_bound - t);
+                double s0 = atol + fabs(y0) * rtol, s1 = atol + fabs(y1) * rtol,
+                       s2 = atol + fabs(y2) * rtol;
+                double d0 = rms3(y0 / s0, y1 / s1, y2 / s2);
+                double d1 = rms3(f0 / s0, f1 / s1, f2 / s2);
+                double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+                if (!(h0 < interval)) h0 = interval;
+                double e0, e1, e2, cdummy;
+                C.rhs(t + h0 * 1.0, y1 + h0 * 1.0 * f1, y2 + h0 * 1.0 * f2, e0, e1, e2, cdummy);
+                double d2 = rms3((e0 - f0) / s0, (e1 - f1) / s1, (e2 - f2) / s2) / h0;
+                double h1;
+                if (d1 <= 1e-15 && d2 <= 1e-15) {
+                    h1 = h0 * 1e-3;
+                    if (!(h1 > 1e-6)) h1 = 1e-6;
+                } else {
+                    h1 = pow(0.01 / ((d2 > d1) ? d2 : d1), 1.0 / 5.0);
+                }
+                h_abs = 100 * h0;
+                if (h1 < h_abs) h_abs = h1;
+                if (interval < h_abs) h_abs = interval;
+                // g = [event(t0, y0) ...], SCIPY/ivp.py:649
+                g = C.events(t, y1, y2, c);
+                rejected = false;
+                need_init = false;
+                if (save) {
+                    jnext = nearest_sample(a.r_save, S, a.x0, a.inv_dsave, t);
+                    rnext = a.r_save[jnext];
+                }
+            }
+
+            // ---- one attempt of RK45._step_impl, SCIPY/rk.py:111-176 ----
+            double min_step = 10 * fabs(nextafter(t, INFINITY) - t);
+            if (!rejected && h_abs < min_step) h_abs = min_step;  // clamp only on entry
+            bool too_small = h_abs < min_step;
+            double h = h_abs;
+            double t_new = t + h;
+            if ((t_new - t_bound) > 0) t_new = t_bound;
+            h = t_new - t;
+            h_abs = fabs(h);
+
+            // rk_step, SCIPY/rk.py:14-71 (K1 = f by FSAL)
+            double k20, k21, k22, k30, k31, k32, k40, k41, k42, k50, k51, k52, k60, k61, k62, k70,
+                k71, k72, cs;
+            C.rhs(t + C2 * h, y1 + (f1 * A21) * h, y2 + (f2 * A21) * h, k20, k21, k22, cs);
+            C.rhs(t + C3 * h, y1 + (f1 * A31 + k21 * A32) * h, y2 + (f2 * A31 + k22 * A32) * h, k30,
+                  k31, k32, cs);
+            C.rhs(t + C4 * h, y1 + (f1 * A41 + k21 * A42 + k31 * A43) * h,
+                  y2 + (f2 * A41 + k22 * A42 + k32 * A43) * h, k40, k41, k42, cs);
+            C.rhs(t + C5 * h, y1 + (f1 * A51 + k21 * A52 + k31 * A53 + k41 * A54) * h,
+                  y2 + (f2 * A51 + k22 * A52 + k32 * A53 + k42 * A54) * h, k50, k51, k52, cs);
+            C.rhs(t + 1.0 * h, y1 + (f1 * A61 + k21 * A62 + k31 * A63 + k41 * A64 + k51 * A65) * h,
+                  y2 + (f2 * A61 + k22 * A62 + k32 * A63 + k42 * A64 + k52 * A65) * h, k60, k61, k62,
+                  cs);
+            // y_new = y + h * (K[:-1].T @ B)   (B[1] = 0)
+            double n0 = y0 + h * (f0 * B1 + k30 * B3 + k40 * B4 + k50 * B5 + k60 * B6);
+            double n1 = y1 + h * (f1 * B1 + k31 * B3 + k41 * B4 + k51 * B5 + k61 * B6);
+            double n2 = y2 + h * (f2 * B1 + k32 * B3 + k42 * B4 + k52 * B5 + k62 * B6);
+            double c_new;
+            C.rhs(t + h, n1, n2, k70, k71, k72, c_new);
+            // error estimate, SCIPY/rk.py:106-110,146-147  (E[1] = 0)
+            double sc0 = atol + fmax(fabs(y0), fabs(n0)) * rtol;
+            double sc1 = atol + fmax(fabs(y1), fabs(n1)) * rtol;
+            double sc2 = atol + fmax(fabs(y2), fabs(n2)) * rtol;
+            double er0 = ((f0 * E1 + k30 * E3 + k40 * E4 + k50 * E5 + k60 * E6 + k70 * E7) * h) / sc0;
+            double er1 = ((f1 * E1 + k31 * E3 + k41 * E4 + k51 * E5 + k61 * E6 + k71 * E7) * h) / sc1;
+            double er2 = ((f2 * E1 + k32 * E3 + k42 * E4 + k52 * E5 + k62 * E6 + k72 * E7) * h) / sc2;
+            double error_norm = rms3(er0, er1, er2);
+
+            bool accepted = false;
+            if (too_small) {
+                status = PGR_RAY_STEP_TOO_SMALL;
+            } else if (error_norm < 1) {
+                double factor;
+                if (error_norm == 0) {
+                    factor = MAX_FACTOR;
+                } else {
+                    factor = SAFETY * pow(error_norm, -0.2);
+                    if (!(factor < MAX_FACTOR)) factor = MAX_FACTOR;
+                }
+                if (rejected && !(factor < 1)) factor = 1;
+                h_abs *= factor;
+                accepted = true;
+                rejected = false;
+            } else {
+                double fac = SAFETY * pow(error_norm, -0.2);
+                if (!(fac > MIN_FACTOR)) fac = MIN_FACTOR;
+                h_abs *= fac;
+                rejected = true;
+                n_rej++;
+                if ((int64_t)n_rej + n_steps > 4 * a.max_steps + 4096) status = PGR_RAY_MAX_STEPS;
+            }
+
+            if (accepted) {
+                n_steps++;
+                // events at the new point, SCIPY/ivp.py:671-675 (c at (t_new, y_new) is the FSAL lookup)
+                unsigned g_new = C.events(t_new, n1, n2, c_new);
+                // find_active_events, SCIPY/ivp.py:133-156: values are +-1, so "up" = -1 -> +1,
+                // "down" = +1 -> -1; surface/bottom need "up", vertical/bbox take either
+                unsigned up = (~g) & g_new, down = g & (~g_new);
+                unsigned active = (up & 3u) | ((up | down) & 12u);
+                g = g_new;
+                bool want_samples = save && (jnext < S - 1) && (rnext <= t_new);
+                double t_end = t_new;
+                int ev = -1;
+                Dense D;
+                if (active || want_samples) {
+                    D.t_old = t; D.h = h; D.y0 = y0; D.y1 = y1; D.y2 = y2;
+                    D.q[0][0] = PQ(f0, k30, k40, k50, k60, k70, 0);
+                    D.q[0][1] = PQ(f0, k30, k40, k50, k60, k70, 1);
+                    D.q[0][2] = PQ(f0, k30, k40, k50, k60, k70, 2);
+                    D.q[0][3] = PQ(f0, k30, k40, k50, k60, k70, 3);
+                    D.q[1][0] = PQ(f1, k31, k41, k51, k61, k71, 0);
+                    D.q[1][1] = PQ(f1, k31, k41, k51, k61, k71, 1);
+                    D.q[1][2] = PQ(f1, k31, k41, k51, k61, k71, 2);
+                    D.q[1][3] = PQ(f1, k31, k41, k51, k61, k71, 3);
+                    D.q[2][0] = PQ(f2, k32, k42, k52, k62, k72, 0);
+                    D.q[2][1] = PQ(f2, k32, k42, k52, k62, k72, 1);
+                    D.q[2][2] = PQ(f2, k32, k42, k52, k62, k72, 2);
+                    D.q[2][3] = PQ(f2, k32, k42, k52, k62, k72, 3);
+                }
+                if (active) {
+                    // handle_events + solve_event_equation, SCIPY/ivp.py:51-131: brentq(xtol = rtol =
+                    // 4 EPS) on a +-1 step function == bisection (Q6).  All events are terminal:
+                    // the earliest root wins, ties go to the lowest event index.
+                    const double xtol = 4 * DBL_EPSILON, brtol = 4 * DBL_EPSILON;
+                    double best = 0;
+                    for (int k = 0; k < 4; k++) {
+                        if (!(active & (1u << k))) continue;
+                        double xpre = t, xcur = t_new, xblk = 0;
+                        double ez0, ez1, ez2, ec, ecp;
+                        D.eval(xpre, ez0, ez1, ez2);
+                        C.lookup(xpre, ez1, ec, ecp);
+                        bool fpre = (C.events(xpre, ez1, ez2, ec) >> k) & 1u;
+                        D.eval(xcur, ez0, ez1, ez2);
+                        C.lookup(xcur, ez1, ec, ecp);
+                        bool fcur = (C.events(xcur, ez1, ez2, ec) >> k) & 1u;
+                        if (fpre == fcur) { status = PGR_RAY_EVENT_ERROR; break; }
+                        for (int it = 0; it < 100; it++) {
+                            if (fpre != fcur) xblk = xpre;
+                            double delta = (xtol + brtol * fabs(xcur)) / 2;
+                            double sbis = (xblk - xcur) / 2;
+                            if (fabs(sbis) < delta) break;
+                            xpre = xcur;
+                            fpre = fcur;
+                            if (fabs(sbis) > delta) xcur += sbis;
+                            else xcur += (sbis > 0 ? delta : -delta);
+                            D.eval(xcur, ez0, ez1, ez2);
+                            C.lookup(xcur, ez1, ec, ecp);
+                            fcur = (C.events(xcur, ez1, ez2, ec) >> k) & 1u;
+                        }
+                        if (ev < 0 || xcur < best) { best = xcur; ev = k; }
+                    }
+                    if (status == RUNNING) t_end = best;
+                }
+                // ---- _interpolate_ray, streamed (REF/launch_rays.py:763-772, Q5): samples of the
+                // segment slice [idx1, idx2) that this step's quartic owns ----
+                if (save && status == RUNNING) {
+                    while (jnext < S - 1 && rnext <= t_end) {
+                        double o0, o1, o2;
+                        D.eval(rnext, o0, o1, o2);
+                        Tp[(int64_t)jnext * a.stride_smp] = o0;
+                        Zp[(int64_t)jnext * a.stride_smp] = o1;
+                        Pp[(int64_t)jnext * a.stride_smp] = o2;
+                        jnext++;
+                        rnext = a.r_save[jnext];
+                    }
+                }
+                if (status == RUNNING) {
+                    if (ev < 0) {
+                        t = t_new; y0 = n0; y1 = n1; y2 = n2;
+                        f0 = k70; f1 = k71; f2 = k72;
+                        if ((t - t_bound) >= 0) status = PGR_RAY_OK;  // SCIPY/base.py:197
+                        else if (n_steps > a.max_steps) status = PGR_RAY_MAX_STEPS;
+                    } else {
+                        // terminal event: t = root, y = sol(root) (SCIPY/ivp.py:689-692), then the
+                        // bounce logic of REF/launch_rays.py:432-480
+                        double r0, r1, r2;
+                        D.eval(t_end, r0, r1, r2);
+                        t = t_end; y0 = r0; y1 = r1; y2 = r2;
+                        if (ev == 2) status = PGR_RAY_VERTICAL;
+                        else if (ev == 3) status = PGR_RAY_BBOX;
+                        else {
+                            double c, cp;
+                            C.lookup(t, y1, c, cp);
+                            double theta = asin(y2 * c) * (180.0 / M_PI);  // ray_angle
+                            double theta_b;
+                            if (ev == 0) {
+                                theta_b = -theta;
+                                ns++;
+                            } else {
+                                // beta = interp1d(depth_ranges, bottom_angles, 'cubic')(x)
+                                const double* xr = env.depth_ranges;
+                                if (!(t >= xr[0] && t <= xr[env.nb - 1])) {
+                                    status = PGR_RAY_BETA_RANGE;
+                                    theta_b = 0;
+                                } else {
+                                    int i = cell_search(t, xr, env.nb);
+                                    double u = t - xr[i];
+                                    const double* q = env.pp + 4 * i;
+                                    double beta = q[0] + u * (q[1] + u * (q[2] + u * q[3]));
+                                    theta_b = 2 * beta - theta;
+                                    nb++;
+                                }
+                            }
+                            if (status == RUNNING) {
+                                if ((a.flags & PGR_TERMINATE_BACKWARDS) && (fabs(theta_b) > 90))
+                                    status = PGR_RAY_BACKWARD;
+                                else {
+                                    y2 = sin(theta_b * (M_PI / 180.0)) / c;
+                                    need_init = true;
+                                    if (!(t < t_bound)) status = PGR_RAY_OK;
+                                    else if (n_steps > a.max_steps) status = PGR_RAY_MAX_STEPS;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    if (valid) {
+        bool ok = (status == PGR_RAY_OK);
+        double nan = __longlong_as_double(0x7ff8000000000000LL);
+        if (save) {
+            if (ok) {
+                // last column = exact final state (REF/launch_rays.py:775-777)
+                Tp[(int64_t)(S - 1) * a.stride_smp] = y0;
+                Zp[(int64_t)(S - 1) * a.stride_smp] = y1;
+                Pp[(int64_t)(S - 1) * a.stride_smp] = y2;
+            } else {
+                for (int j = 0; j < S; j++) {
+                    Tp[(int64_t)j * a.stride_smp] = nan;
+                    Zp[(int64_t)j * a.stride_smp] = nan;
+                    Pp[(int64_t)j * a.stride_smp] = nan;
+                }
+            }
+        }
+        if (a.end_state) {
+            a.end_state[3 * ray + 0] = ok ? y0 : nan;
+            a.end_state[3 * ray + 1] = ok ? y1 : nan;
+            a.end_state[3 * ray + 2] = ok ? y2 : nan;
+        }
+        a.n_bott[ray] = nb;
+        a.n_surf[ray] = ns;
+        a.status[ray] = status;
+        if (a.n_steps) a.n_steps[ray] = n_steps;
+        if (a.n_rej) a.n_rej[ray] = n_rej;
+    }
+}
+
+// unit-level evaluation of a1-a8 at arbitrary points (parity tests)
+__global__ void pgr_eval_kernel(EnvDev env, const double* x, const double* y, int64_t M, double* out)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= M) return;
+    const Ctx<false> C(env, nullptr);
+    double d0, d1, d2, c;
+    C.rhs(x[k], y[3 * k + 1], y[3 * k + 2], d0, d1, d2, c);
+    double* o = out + 10 * k;
+    o[0] = d0; o[1] = d1; o[2] = d2; o[3] = c;
+    o[4] = asin(y[3 * k + 2] * c) * (180.0 / M_PI);
+    unsigned g = C.events(x[k], y[3 * k + 1], y[3 * k + 2], c);
+    for (int q = 0; q < 4; q++) o[5 + q] = ((g >> q) & 1u) ? 1.0 : -1.0;
+    o[9] = C.bathy(x[k]);
+}
+
+// ====================================================================================
+// host side
+// ====================================================================================
+static thread_local std::string g_err;
+static int g_waves_per_block = 0;
+
+static int fail(const std::string& m)
+{
+    g_err = m;
+    return -1;
+}
+#define HIPCHK(call)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(std::string(#call) + ": " + hipGetErrorString(e_));                \
+    } while (0)
+
+struct pgr_env {
+    int device = 0;
+    EnvDev d{};
+    int range_indep = 0;
+    int lds_path = 0;
+    std::vector<void*> allocs;
+    int num_cus = 256;
+    size_t max_lds = 64 * 1024;
+};
+
+extern "C" const char* pgr_last_error(void) { return g_err.c_str(); }
+
+extern "C" int pgr_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { fail("hipGetDeviceCount failed"); return -1; }
+    return n;
+}
+
+extern "C" int pgr_set_waves_per_block(int waves)
+{
+    if (waves < 0 || waves > 8) return fail("waves per block must be in [0,8]");
+    g_waves_per_block = waves;
+    return 0;
+}
+
+// grid[j] == g0 + j*dg for all j, evaluated exactly as the device does (mul, then add)
+static bool exactly_uniform(const double* g, int64_t n, double& g0, double& dg)
+{
+    if (n < 2) return false;
+    g0 = g[0];
+    dg = g[1] - g[0];
+    if (!(dg > 0) || !std::isfinite(dg)) return false;
+    for (int64_t j = 0; j < n; j++) {
+        volatile double m = (double)j * dg;
+        volatile double v = g0 + m;
+        if (v != g[j]) return false;
+    }
+    return true;
+}
+
+// Not-a-knot cubic through (x, y): scipy.interpolate.interp1d(kind="cubic") ==
+// make_interp_spline(k=3, bc_type=None) (REF/launch_rays.py:397-399).  Built in
+// piecewise-polynomial form with the standard not-a-knot end rows; pp[4i..] = {y_i, s_i, c2, c3}.
+static bool build_notaknot(const double* x, const double* y, int64_t n, std::vector<double>& pp)
+{
+    if (n < 4) return false;
+    std::vector<double> dx(n), sl(n), lo(n), di(n), up(n), b(n);
+    for (int64_t i = 0; i < n - 1; i++) {
+        dx[i] = x[i + 1] - x[i];
+        sl[i] = (y[i + 1] - y[i]) / dx[i];
+    }
+    for (int64_t i = 1; i < n - 1; i++) {
+        lo[i] = dx[i];
+        di[i] = 2 * (dx[i - 1] + dx[i]);
+        up[i] = dx[i - 1];
+        b[i] = 3 * (dx[i] * sl[i - 1] + dx[i - 1] * sl[i]);
+    }
+    double d = x[2] - x[0];
+    di[0] = dx[1]; up[0] = d; lo[0] = 0;
+    b[0] = ((dx[0] + 2 * d) * dx[1] * sl[0] + dx[0] * dx[0] * sl[1]) / d;
+    d = x[n - 1] - x[n - 3];
+    di[n - 1] = dx[n - 3]; lo[n - 1] = d; up[n - 1] = 0;
+    b[n - 1] = (dx[n - 2] * dx[n - 2] * sl[n - 3] + (2 * d + dx[n - 2]) * dx[n - 3] * sl[n - 2]) / d;
+    for (int64_t i = 1; i < n; i++) {
+        double m = lo[i] / di[i - 1];
+        di[i] -= m * up[i - 1];
+        b[i] -= m * b[i - 1];
+    }
+    b[n - 1] /= di[n - 1];
+    for (int64_t i = n - 2; i >= 0; i--) b[i] = (b[i] - up[i] * b[i + 1]) / di[i];
+    pp.assign(4 * (size_t)(n - 1), 0.0);
+    for (int64_t i = 0; i < n - 1; i++) {
+        pp[4 * i + 0] = y[i];
+        pp[4 * i + 1] = b[i];
+        pp[4 * i + 2] = (3 * sl[i] - 2 * b[i] - b[i + 1]) / dx[i];
+        pp[4 * i + 3] = (b[i] + b[i + 1] - 2 * sl[i]) / (dx[i] * dx[i]);
+    }
+    return true;
+}
+
+template <class T>
+static int upload(pgr_env* e, const T* host, size_t count, const T** dev)
+{
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, count * sizeof(T)));
+    e->allocs.push_back(p);
+    HIPCHK(hipMemcpy(p, host, count * sizeof(T), hipMemcpyHostToDevice));
+    *dev = (const T*)p;
+    return 0;
+}
+
+extern "C" void pgr_env_destroy(pgr_env* env)
+{
+    if (!env) return;
+    (void)hipSetDevice(env->device);
+    for (void* p : env->allocs) (void)hipFree(p);
+    delete env;
+}
+
+extern "C" int pgr_env_create(pgr_env** out, int device, const double* cin, const double* cpin,
+                              const double* rin, const double* zin, int64_t nr, int64_t nz,
+                              const double* depths, const double* depth_ranges,
+                              const double* bottom_angles, int64_t nb)
+{
+    if (!out || !cin || !cpin || !rin || !zin || !depths || !depth_ranges || !bottom_angles)
+        return fail("pgr_env_create: null argument");
+    if (nr < 2 || nz < 2) return fail("sound speed table needs at least 2 range and 2 depth points");
+    if (nr > (1 << 30) || nz > (1 << 30) || nb > (1 << 30)) return fail("table too large");
+    if (nb < 4) return fail("x and y arrays must have at least 4 entries");  // interp1d(kind='cubic')
+    // REF/launch_rays.py:79-90
+    for (int64_t i = 1; i < nr; i++)
+        if (!(rin[i] - rin[i - 1] >= 0))
+            return fail("Sound speed range coordinates must be monotonically increasing.");
+    for (int64_t i = 1; i < nz; i++)
+        if (!(zin[i] - zin[i - 1] >= 0))
+            return fail("Sound speed depth coordinates must be monotonically increasing.");
+    for (int64_t i = 1; i < nb; i++)
+        if (!(depth_ranges[i] - depth_ranges[i - 1] >= 0))
+            return fail("Bathymetry range coordinates must be monotonically increasing.");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail("pgr_env_create: no such HIP device");
+    HIPCHK(hipSetDevice(device));
+
+    pgr_env* e = new pgr_env();
+    e->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        e->num_cus = prop.multiProcessorCount;
+        e->max_lds = prop.sharedMemPerBlock;
+        if (strncmp(prop.gcnArchName, "gfx950", 6) == 0) e->max_lds = 160 * 1024;  // CDNA4 LDS per CU
+    }
+    int optin = 0;
+    if (hipDeviceGetAttribute(&optin, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess &&
+        (size_t)optin > e->max_lds)
+        e->max_lds = (size_t)optin;
+
+    // range independence: every row bitwise equal to row 0 (both tables)
+    bool indep = true;
+    for (int64_t i = 1; i < nr && indep; i++)
+        indep = memcmp(cin + i * nz, cin, sizeof(double) * nz) == 0 &&
+                memcmp(cpin + i * nz, cpin, sizeof(double) * nz) == 0;
+    e->range_indep = indep;
+    size_t rows = indep ? 1 : (size_t)nr;
+    std::vector<double2> tab(rows * (size_t)nz);
+    for (size_t i = 0; i < rows; i++)
+        for (int64_t j = 0; j < nz; j++) tab[i * nz + j] = make_double2(cin[i * nz + j], cpin[i * nz + j]);
+    e->lds_path = indep && ((size_t)nz * sizeof(double2) <= e->max_lds);
+    std::vector<double> pp;
+    if (!build_notaknot(depth_ranges, bottom_angles, nb, pp)) {
+        delete e;
+        return fail("x and y arrays must have at least 4 entries");
+    }
+    EnvDev& d = e->d;
+    int rc = 0;
+    rc |= upload(e, tab.data(), tab.size(), &d.tab);
+    rc |= upload(e, rin, (size_t)nr, &d.rin);
+    rc |= upload(e, zin, (size_t)nz, &d.zin);
+    rc |= upload(e, depths, (size_t)nb, &d.depths);
+    rc |= upload(e, depth_ranges, (size_t)nb, &d.depth_ranges);
+    rc |= upload(e, pp.data(), pp.size(), &d.pp);
+    if (rc) { pgr_env_destroy(e); return -1; }
+    d.nr = (int)nr; d.nz = (int)nz; d.nb = (int)nb;
+    d.row_stride = indep ? 0 : (int)nz;
+    d.z_uniform = exactly_uniform(zin, nz, d.z0, d.dz);
+    d.inv_dz = d.z_uniform ? 1.0 / d.dz : 0.0;
+    d.r_uniform = exactly_uniform(rin, nr, d.r0, d.dr);
+    d.inv_dr = d.r_uniform ? 1.0 / d.dr : 0.0;
+    d.b_uniform = exactly_uniform(depth_ranges, nb, d.b0, d.db);
+    d.inv_db = d.b_uniform ? 1.0 / d.db : 0.0;
+    const double tol = 1e-6;
+    d.zhi_tol = zin[nz - 1] + tol;
+    d.zlo_tol = zin[0] - tol;
+    d.rlo_tol = rin[0] - tol;
+    d.rhi_tol = rin[nr - 1] + tol;
+    *out = e;
+    return 0;
+}
+
+extern "C" int pgr_env_query(const pgr_env* env, int what)
+{
+    if (!env) return fail("null env");
+    switch (what) {
+    case 0: return env->range_indep;
+    case 1: return env->d.z_uniform;
+    case 2: return env->d.r_uniform;
+    case 3: return env->lds_path;
+    case 4: return env->device;
+    default: return fail("pgr_env_query: unknown property");
+    }
+}
+
+extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, double source_range,
+                                    double receiver_range, const double* r_save, int32_t S,
+                                    double rtol, double atol, uint32_t flags, int64_t max_steps,
+                                    double* T, double* z, double* p, double* end_state,
+                                    int32_t* n_bott, int32_t* n_surf, int32_t* status,
+                                    int32_t* n_steps, int32_t* n_rej, void* stream)
+{
+    if (!env) return fail("pgr_shoot_fan: null env");
+    if (N < 0) return fail("pgr_shoot_fan: negative ray count");
+    if (N == 0) return 0;
+    if (!y0 || !n_bott || !n_surf || !status) return fail("pgr_shoot_fan: null argument");
+    bool save = (T != nullptr);
+    if (save && (!z || !p || !r_save)) return fail("pgr_shoot_fan: T, z, p and r_save go together");
+    if (save && S < 1) return fail("pgr_shoot_fan: num_range_save must be >= 1");
+    if (!(rtol > 0) || !(atol >= 0)) return fail("pgr_shoot_fan: bad tolerances");
+    if (max_steps <= 0 || max_steps > (1LL << 30)) return fail("pgr_shoot_fan: max_steps out of range");
+    // REF/launch_rays.py:404: an empty `while x < receiver_range` leaves `sols` empty and the
+    // reference fails with IndexError; backwards shots are mirrored by the caller first
+    if (!(source_range < receiver_range)) return fail("pgr_shoot_fan: need source_range < receiver_range (mirror backwards shots)");
+    HIPCHK(hipSetDevice(env->device));
+
+    FanArgs a{};
+    a.y0 = y0; a.r_save = r_save; a.T = T; a.Z = z; a.P = p; a.end_state = end_state;
+    a.n_bott = n_bott; a.n_surf = n_surf; a.status = status; a.n_steps = n_steps; a.n_rej = n_rej;
+    a.N = N; a.S = save ? S : 1;
+    if (flags & PGR_SAMPLE_MAJOR) { a.stride_ray = 1; a.stride_smp = N; }
+    else { a.stride_ray = S; a.stride_smp = 1; }
+    a.x0 = source_range; a.x1 = receiver_range; a.rtol = rtol; a.atol = atol;
+    a.inv_dsave = (S > 1 && receiver_range != source_range) ? (double)(S - 1) / (receiver_range - source_range) : 0.0;
+    a.max_steps = max_steps; a.flags = flags;
+
+    int64_t waves = (N + 63) / 64;
+    hipStream_t st = (hipStream_t)stream;
+    if (env->lds_path) {
+        // one workgroup per CU (the LDS table is per workgroup): the smallest workgroup that
+        // covers the fan in a single round, capped at 16 waves
+        int wpb = g_waves_per_block;
+        if (wpb == 0) {
+            wpb = (int)((waves + env->num_cus - 1) / env->num_cus);
+            if (wpb < 1) wpb = 1;
+            if (wpb > 8) wpb = 8;
+        }
+        int threads = wpb * 64;
+        int64_t blocks = (N + threads - 1) / threads;
+        size_t lds = (size_t)env->d.nz * sizeof(double2);
+        HIPCHK(hipFuncSetAttribute((const void*)pgr_fan_kernel<true>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(pgr_fan_kernel<true>, dim3((unsigned)blocks), dim3(threads), lds, st, env->d, a);
+    } else {
+        int wpb = g_waves_per_block ? g_waves_per_block : 4;
+        int threads = wpb * 64;
+        int64_t blocks = (N + threads - 1) / threads;
+        hipLaunchKernelGGL(pgr_fan_kernel<false>, dim3((unsigned)blocks), dim3(threads), 0, st, env->d, a);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8) == hipSuccess ? 0 : -1; }
+};
+}  // namespace
+
+extern "C" int pgr_shoot_fan(pgr_env* env, const double* y0, int64_t N, double source_range,
+                             double receiver_range, const double* r_save, int32_t S, double rtol,
+                             double atol, uint32_t flags, int64_t max_steps, double* T, double* z,
+                             double* p, double* end_state, int32_t* n_bott, int32_t* n_surf,
+                             int32_t* status, int32_t* n_steps, int32_t* n_rej)
+{
+    if (!env) return fail("pgr_shoot_fan: null env");
+    if (N < 0) return fail("pgr_shoot_fan: negative ray count");
+    if (N == 0) return 0;
+    if (!y0 || !n_bott || !n_surf || !status) return fail("pgr_shoot_fan: null argument");
+    bool save = (T != nullptr);
+    if (save && (!z || !p || !r_save || S < 1)) return fail("pgr_shoot_fan: T, z, p, r_save, S go together");
+    HIPCHK(hipSetDevice(env->device));
+    DevBuf dy0, dr, dT, dZ, dP, dE, dnb, dns, dst, dn1, dn2;
+    size_t ns_bytes = (size_t)N * (size_t)(save ? S : 0) * sizeof(double);
+    if (dy0.alloc(N * 3 * sizeof(double)) || dr.alloc((save ? S : 1) * sizeof(double)) ||
+        dT.alloc(ns_bytes) || dZ.alloc(ns_bytes) || dP.alloc(ns_bytes) ||
+        dE.alloc(N * 3 * sizeof(double)) || dnb.alloc(N * 4) || dns.alloc(N * 4) || dst.alloc(N * 4) ||
+        dn1.alloc(N * 4) || dn2.alloc(N * 4))
+        return fail("pgr_shoot_fan: device allocation failed");
+    HIPCHK(hipMemcpy(dy0.p, y0, N * 3 * sizeof(double), hipMemcpyHostToDevice));
+    if (save) HIPCHK(hipMemcpy(dr.p, r_save, (size_t)S * sizeof(double), hipMemcpyHostToDevice));
+    int rc = pgr_shoot_fan_device(env, (const double*)dy0.p, N, source_range, receiver_range,
+                                  (const double*)dr.p, S, rtol, atol, flags, max_steps,
+                                  save ? (double*)dT.p : nullptr, save ? (double*)dZ.p : nullptr,
+                                  save ? (double*)dP.p : nullptr, (double*)dE.p, (int32_t*)dnb.p,
+                                  (int32_t*)dns.p, (int32_t*)dst.p, (int32_t*)dn1.p, (int32_t*)dn2.p,
+                                  nullptr);
+    if (rc) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    if (save) {
+        HIPCHK(hipMemcpy(T, dT.p, ns_bytes, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(z, dZ.p, ns_bytes, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(p, dP.p, ns_bytes, hipMemcpyDeviceToHost));
+    }
+    if (end_state) HIPCHK(hipMemcpy(end_state, dE.p, N * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(n_bott, dnb.p, N * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(n_surf, dns.p, N * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(status, dst.p, N * 4, hipMemcpyDeviceToHost));
+    if (n_steps) HIPCHK(hipMemcpy(n_steps, dn1.p, N * 4, hipMemcpyDeviceToHost));
+    if (n_rej) HIPCHK(hipMemcpy(n_rej, dn2.p, N * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int pgr_eval_points(pgr_env* env, const double* x, const double* y, int64_t M, double* out10)
+{
+    if (!env || !x || !y || !out10) return fail("pgr_eval_points: null argument");
+    if (M <= 0) return 0;
+    HIPCHK(hipSetDevice(env->device));
+    DevBuf dx, dy, dout;
+    if (dx.alloc(M * 8) || dy.alloc(M * 24) || dout.alloc(M * 80)) return fail("device allocation failed");
+    HIPCHK(hipMemcpy(dx.p, x, M * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dy.p, y, M * 24, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(pgr_eval_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, 0, env->d,
+                       (const double*)dx.p, (const double*)dy.p, M, (double*)dout.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out10, dout.p, M * 80, hipMemcpyDeviceToHost));
+    return 0;
+}
