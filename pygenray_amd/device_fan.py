@@ -1,0 +1,76 @@
+"""Device-resident fan launches: inputs and outputs stay in HBM.
+
+PyTorch is plumbing only here (device memory + the current HIP stream): the tensors'
+``data_ptr()`` go straight into ``pgr_shoot_fan_device`` (include/pgr.h).  Used by bench.py
+(whole-job throughput with inputs already resident) and by the multi-GPU driver.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from .environment import _unpack_envi
+from .host_physics import bilinear_interp
+
+
+class DeviceFan:
+    """Buffers for one fan of N rays on ``device`` and a ``run()`` that enqueues the kernel."""
+
+    def __init__(self, env_handle, y0, source_range, receiver_range, num_range_save, rtol=1e-9,
+                 atol=1e-6, terminate_backwards=True, save=True, sample_major=False,
+                 max_steps=1_000_000):
+        self.env = env_handle
+        dev = torch.device("cuda", env_handle.device)
+        self.dev = dev
+        y0 = np.ascontiguousarray(y0, dtype=np.float64).reshape(-1, 3)
+        self.N, self.S = len(y0), int(num_range_save)
+        self.x0, self.x1 = float(source_range), float(receiver_range)
+        self.rtol, self.atol, self.max_steps = float(rtol), float(atol), int(max_steps)
+        self.flags = (_lib.PGR_TERMINATE_BACKWARDS if terminate_backwards else 0) | \
+            (_lib.PGR_SAMPLE_MAJOR if sample_major else 0)
+        self.save, self.sample_major = save, sample_major
+        f64 = dict(dtype=torch.float64, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.y0 = torch.from_numpy(y0).to(dev)
+        self.r_save = torch.from_numpy(np.linspace(self.x0, self.x1, self.S)).to(dev)
+        if save:
+            shape = (self.S, self.N) if sample_major else (self.N, self.S)
+            self.T = torch.empty(shape, **f64)
+            self.Z = torch.empty(shape, **f64)
+            self.P = torch.empty(shape, **f64)
+        else:
+            self.T = self.Z = self.P = None
+        self.end = torch.empty((self.N, 3), **f64)
+        self.n_bott = torch.empty(self.N, **i32)
+        self.n_surf = torch.empty(self.N, **i32)
+        self.status = torch.empty(self.N, **i32)
+        self.n_steps = torch.empty(self.N, **i32)
+        self.n_rej = torch.empty(self.N, **i32)
+
+    def run(self):
+        """Enqueue one pass of the hot path on torch's current stream (asynchronous)."""
+        ptr = lambda t: 0 if t is None else t.data_ptr()  # noqa: E731
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        self.env.shoot_fan_device(ptr(self.y0), self.N, self.x0, self.x1, ptr(self.r_save), self.S,
+                                  self.rtol, self.atol, self.flags, self.max_steps, ptr(self.T),
+                                  ptr(self.Z), ptr(self.P), ptr(self.end), ptr(self.n_bott),
+                                  ptr(self.n_surf), ptr(self.status), ptr(self.n_steps),
+                                  ptr(self.n_rej), stream)
+
+    def ray_steps(self):
+        return int(self.n_steps.sum(dtype=torch.int64).item())
+
+
+def fan_y0(arrays, source_depth, source_range, ode_angles_deg):
+    """y0 = [0, z_s, sin(theta)/c(x_s, z_s)] per ray (REF/launch_rays.py:140-144)."""
+    cin, _, rin, zin = arrays[:4]
+    c = bilinear_interp(source_range, source_depth, rin, zin, cin)
+    ang = np.asarray(ode_angles_deg, dtype=float)
+    y0 = np.zeros((len(ang), 3))
+    y0[:, 1] = source_depth
+    y0[:, 2] = np.sin(np.radians(ang)) / c
+    return y0
+
+
+def env_handle_from(environment, flatearth=False, device=0):
+    arrs = _unpack_envi(environment, flatearth=flatearth)
+    return _lib.EnvHandle(*arrs, device=device), arrs

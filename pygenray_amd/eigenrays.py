@@ -1,0 +1,106 @@
+"""Eigenray search: bracket detection + regula falsi, batched over all brackets on the GPU.
+
+Mirrors ``pygenray.eigenrays`` (REF = /root/reference/src/pygenray, eigenrays.py:11-268):
+brackets are sign changes of ``z_end + receiver_depth`` between neighbouring fan rays; each
+bracket is refined by false position, re-shooting one trial ray per iteration, until
+``|z_end + receiver_depth| < ztol`` or the iteration budget is spent.  The reference maps
+brackets to a process pool and re-unpacks the environment for every trial ray; here every
+iteration is ONE fan launch holding the trial rays of all still-active brackets.
+"""
+import numpy as np
+
+from .launch_rays import _shoot_ode_angles
+from .ray_objects import RayFan, EigenRays
+
+
+def _regula_falsi_batch(z1, z2, th1, th2, receiver_depth, source_depth, source_range,
+                        receiver_range, num_range_save, environment, ztol, max_iter, kwargs):
+    """Vectorised _find_single_eigenray (REF/eigenrays.py:206-268) for all brackets at once.
+    Returns (found mask, RayFan pieces of the found rays in stored convention)."""
+    rtol = kwargs.get("rtol", 1e-9)
+    terminate_backwards = kwargs.get("terminate_backwards", True)
+    flatearth = kwargs.get("flatearth", True)
+    device = kwargs.get("device", 0)
+    nbk = len(z1)
+    z1, z2, th1, th2 = (np.array(a, dtype=float) for a in (z1, z2, th1, th2))
+    theta = th1 - (z1 + receiver_depth) * (th2 - th1) / (z2 - z1)  # REF/eigenrays.py:118-120
+    active = np.ones(nbk, bool)
+    found = np.zeros(nbk, bool)
+    S = int(num_range_save)
+    T = np.zeros((nbk, S)); Z = np.zeros((nbk, S)); P = np.zeros((nbk, S))
+    nb = np.zeros(nbk, np.int64); ns = np.zeros(nbk, np.int64)
+    th_found = np.zeros(nbk)
+    r = None
+    iter_count = 0
+    while active.any():
+        idx = np.where(active)[0]
+        # shoot_ray(theta): ODE angle = -theta (REF/launch_rays.py:251)
+        out = _shoot_ode_angles(source_depth, source_range, -theta[idx], receiver_range, S,
+                                environment, rtol, terminate_backwards, flatearth, device=device)
+        r = out["r"]
+        dropped = out["status"] != 0
+        zend = -out["z"][:, -1]  # stored convention ray.z[-1]
+        for q in idx[dropped]:
+            # REF/eigenrays.py:241-245
+            print(f"Failed to find eigen ray for receiver depth {receiver_depth} [m] and "
+                  f"approximate launch angle {theta[q]} [m] ray θ = 90°")
+        active[idx[dropped]] = False
+        hit = (~dropped) & (np.abs(zend + receiver_depth) < ztol)
+        hq = idx[hit]
+        T[hq], Z[hq], P[hq] = out["T"][hit], -out["z"][hit], -out["p"][hit]
+        nb[hq], ns[hq] = out["n_bott"][hit], out["n_surf"][hit]
+        th_found[hq] = theta[hq]  # launch_angle flipped back (REF/eigenrays.py:249)
+        found[hq] = True
+        active[hq] = False
+        go = (~dropped) & (~hit)
+        gq = idx[go]
+        zg = zend[go]
+        same = np.sign(zg + receiver_depth) == np.sign(z1[gq] + receiver_depth)
+        z1[gq[same]] = zg[same]
+        th1[gq[same]] = theta[gq[same]]
+        z2[gq[~same]] = zg[~same]
+        th2[gq[~same]] = theta[gq[~same]]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            theta[gq] = th1[gq] - (z1[gq] + receiver_depth) * (th2[gq] - th1[gq]) / (z2[gq] - z1[gq])
+        if iter_count > max_iter:  # REF/eigenrays.py:265-268
+            active[gq] = False
+        iter_count += 1
+    return found, th_found, r, T, Z, P, nb, ns
+
+
+def find_eigenrays(rays, receiver_depths, source_depth, source_range, receiver_range,
+                   num_range_save, environment, ztol=1, max_iter=20, num_workers=None, **kwargs):
+    """Find eigenrays from an initial ray fan by regula falsi (REF/eigenrays.py:11-203).
+
+    ``num_workers`` is accepted and ignored.  ``kwargs`` are those of ``shoot_ray``
+    (``rtol, terminate_backwards, debug, flatearth``).  Returns ``EigenRays``."""
+    erays_dict, num_eigenrays, num_found, failed = {}, {}, {}, {}
+    for rd_idx, receiver_depth in enumerate(receiver_depths):
+        # REF/eigenrays.py:65-79
+        depth_sign = np.sign(rays.zs[:, -1] + receiver_depth)
+        starts = np.where(np.diff(depth_sign))[0]
+        num_eigenrays[receiver_depth] = len(starts)
+        z1s, z2s = rays.zs[starts, -1], rays.zs[starts + 1, -1]
+        th1s, th2s = rays.thetas[starts], rays.thetas[starts + 1]
+        failed[rd_idx] = []
+        if len(starts) == 0:
+            erays_dict[rd_idx] = RayFan.from_arrays(
+                np.zeros(0), np.zeros((0, num_range_save)), np.zeros((0, num_range_save)),
+                np.zeros((0, num_range_save)), np.zeros((0, num_range_save)), np.zeros(0, np.int64),
+                np.zeros(0, np.int64), np.zeros(0))
+            num_found[rd_idx] = 0
+            continue
+        found, th, r, T, Z, P, nb, ns = _regula_falsi_batch(
+            z1s, z2s, th1s, th2s, receiver_depth, source_depth, source_range, receiver_range,
+            num_range_save, environment, ztol, max_iter, kwargs)
+        for k in np.where(~found)[0]:
+            failed[rd_idx].append((th1s[k], th2s[k]))
+        M = int(found.sum())
+        erays_dict[rd_idx] = RayFan.from_arrays(
+            th[found], np.tile(r, (M, 1)), T[found], Z[found], P[found], nb[found], ns[found],
+            np.full(M, source_depth))
+        num_found[rd_idx] = M
+    return EigenRays(receiver_depths, erays_dict, environment, num_eigenrays, num_found, failed)
+
+
+__all__ = ["find_eigenrays"]

@@ -1,0 +1,72 @@
+"""Scalar table look-ups needed on the HOST side of the boundary.
+
+The reference computes a few one-off scalars outside its integration loop with the same
+functions it uses inside it: the sound speed at the source for ``y0``
+(REF/launch_rays.py:140,284) and the received angle of an eigenray (REF/ray_objects.py:521-528).
+These are restated here in NumPy with the reference's exact arithmetic
+(REF/integration_processes.py:101-235, 306-334) so ``y0`` is bit-identical to pygenray's.
+They are *not* a CPU path for the integrator: everything per-step runs in the HIP kernels;
+``derivsrd`` and the event functions of the reference's public API are evaluated on the GPU
+through ``pgr_eval_points``.
+"""
+import numpy as np
+
+
+def _cell(grid, q):
+    k = int(np.searchsorted(grid, q)) - 1  # side='left'
+    return max(0, min(k, len(grid) - 2))
+
+
+def bilinear_interp(x, y, x_grid, y_grid, values):
+    """REF/integration_processes.py:101-174 (index clamped, weights not: extrapolates, Q4)."""
+    i = _cell(x_grid, x)
+    j = _cell(y_grid, y)
+    wx = (x - x_grid[i]) / (x_grid[i + 1] - x_grid[i])
+    wy = (y - y_grid[j]) / (y_grid[j + 1] - y_grid[j])
+    return ((1 - wx) * (1 - wy) * values[i, j] + wx * (1 - wy) * values[i + 1, j]
+            + (1 - wx) * wy * values[i, j + 1] + wx * wy * values[i + 1, j + 1])
+
+
+def linear_interp(x, xin, yin):
+    """REF/integration_processes.py:177-235."""
+    i = _cell(xin, x)
+    w = (x - xin[i]) / (xin[i + 1] - xin[i])
+    return (1 - w) * yin[i] + w * yin[i + 1]
+
+
+def ray_angle(x, y, cin, rin, zin):
+    """(theta [deg], c) at a ray state; NaN angle when |p c| > 1 (REF/integration_processes.py:306-334)."""
+    c = bilinear_interp(x, y[1], rin, zin, cin)
+    theta = np.degrees(np.arcsin(y[2] * c))
+    return theta, c
+
+
+def _device_eval(x, y, cin, cpin, rin, zin, depths, depth_ranges):
+    from ._lib import EnvHandle
+    nb = len(depths)
+    env = EnvHandle(cin, cpin, rin, zin, depths, depth_ranges, np.zeros(nb))
+    try:
+        return env.eval_points(np.atleast_1d(np.asarray(x, float)), np.asarray(y, float).reshape(-1, 3))
+    finally:
+        env.close()
+
+
+def derivsrd(x, y, cin, cpin, rin, zin, depths, depth_ranges):
+    """Ray-equation right-hand side [dT/dx, dz/dx, dp/dx] (REF/integration_processes.py:26-98),
+    evaluated by the HIP kernel's own ``rhs``."""
+    return _device_eval(x, y, cin, cpin, rin, zin, depths, depth_ranges)[0, 0:3]
+
+
+def _event(k):
+    def f(x, y, cin, cpin, rin, zin, depths, depth_ranges):
+        return float(_device_eval(x, y, cin, cpin, rin, zin, depths, depth_ranges)[0, 5 + k])
+    return f
+
+
+surface_bounce = _event(0)          # REF/integration_processes.py:238-250
+bottom_bounce = _event(1)           # REF/integration_processes.py:253-266
+vertical_ray = _event(2)            # REF/integration_processes.py:269-277
+ray_bounding_box_event = _event(3)  # REF/integration_processes.py:280-303
+
+__all__ = ["derivsrd", "bottom_bounce", "surface_bounce", "ray_bounding_box_event", "ray_angle",
+           "bilinear_interp", "linear_interp", "vertical_ray"]

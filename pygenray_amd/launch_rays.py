@@ -1,0 +1,128 @@
+"""``shoot_rays`` / ``shoot_ray``: pygenray's fan and single-ray entry points on the HIP path.
+
+Mirrors ``pygenray.launch_rays`` (REF = /root/reference/src/pygenray): same names, arguments,
+defaults, sign conventions and error behaviour as REF/launch_rays.py:11-322; the per-ray
+spawn pool + shared-memory transport (REF/launch_rays.py:133-198, multi_processing.py) is
+replaced by one table upload per environment and one kernel launch per fan.
+"""
+import numpy as np
+
+from . import _lib
+from .environment import _unpack_envi, _mirror_envi_arrays, _check_monotone
+from .host_physics import bilinear_interp
+from .ray_objects import Ray, RayFan
+
+_DROP_MSG = {
+    1: "ray is vertical, terminating integration",
+    2: "ray left bounding box, terminating integration",
+    3: "ray bounced backwards, terminating integration",
+    4: "Integration failed with message: Required step size is less than spacing between numbers.",
+    5: "ray exceeded the step limit, terminating integration",
+    6: "Error in ray integration: A value in x_new is outside the interpolation range.",
+    7: "Error in ray integration: f(a) and f(b) must have different signs",
+}
+
+
+def _device_env(environment, flatearth, backwards, device=0):
+    """EnvHandle (tables resident in HBM) for this environment, cached on it."""
+    cache = getattr(environment, "_cache", None)
+    if cache is None:
+        cache = environment._cache = {}
+    key = ("dev", bool(flatearth), bool(backwards), int(device))
+    if key not in cache:
+        cin, cpin, rin, zin, depths, depth_ranges, bottom_angles = _unpack_envi(
+            environment, flatearth=flatearth)
+        _check_monotone(rin, zin, depth_ranges)
+        if backwards:
+            cin, cpin, rin, depths, depth_ranges, bottom_angles = _mirror_envi_arrays(
+                cin, cpin, rin, depths, depth_ranges, bottom_angles)
+        cache[key] = (_lib.EnvHandle(cin, cpin, rin, zin, depths, depth_ranges, bottom_angles,
+                                     device=device), (cin, rin, zin))
+    return cache[key]
+
+
+def _shoot_ode_angles(source_depth, source_range, ode_angles_deg, receiver_range, num_range_save,
+                      environment, rtol, terminate_backwards, flatearth, device=0, save=True,
+                      max_steps=1_000_000):
+    """Batched _shoot_single_ray_process (REF/launch_rays.py:487-590): ODE-convention launch
+    angles in, ODE-convention SoA out (in the mirrored frame for backwards shots)."""
+    backwards = receiver_range < source_range
+    env, (cin, rin, zin) = _device_env(environment, flatearth, backwards, device)
+    if backwards:
+        source_range_i, receiver_range_i = -source_range, -receiver_range
+    else:
+        source_range_i, receiver_range_i = source_range, receiver_range
+    # REF/launch_rays.py:140-144
+    c = bilinear_interp(source_range_i, source_depth, rin, zin, cin)
+    ang = np.asarray(ode_angles_deg, dtype=float).reshape(-1)
+    y0 = np.zeros((len(ang), 3))
+    y0[:, 1] = source_depth
+    y0[:, 2] = np.sin(np.radians(ang)) / c
+    if not (source_range_i < receiver_range_i):
+        # the reference's bounce loop never runs and _interpolate_ray indexes an empty list
+        raise IndexError("list index out of range")
+    out = env.shoot_fan(y0, source_range_i, receiver_range_i, num_range_save, rtol=rtol,
+                        terminate_backwards=terminate_backwards, save=save, max_steps=max_steps)
+    if backwards:
+        out["r"] = -out["r"]
+    return out
+
+
+def _report_drops(status, debug):
+    if debug:
+        for s in status[status != 0]:
+            print(_DROP_MSG.get(int(s), f"ray dropped (status {int(s)})"))
+
+
+def shoot_rays(source_depth, source_range, launch_angles, receiver_range, num_range_save,
+               environment, rtol=1e-9, terminate_backwards=True, n_processes=None, debug=True,
+               flatearth=True, device=0):
+    """Integrate a fan of rays (REF/launch_rays.py:11-200) -> ``RayFan``.
+
+    ``n_processes`` is accepted for compatibility and ignored (the fan is one GPU launch).
+    Launch-angle sign: like the reference, a fan of fewer than 70 angles is integrated with
+    ODE angle = +user angle and a larger fan with ODE angle = -user angle (Q1 in SURVEY.md:
+    REF/launch_rays.py:67,94,251); dropped rays vanish from the fan (Q12)."""
+    if type(launch_angles) is list:
+        launch_angles = np.array(launch_angles)
+    launch_angles = -np.asarray(launch_angles, dtype=float)
+    n = len(launch_angles)
+    if n < 70:
+        ode = -launch_angles     # shoot_ray flips the (already flipped) angle again
+        stored = ode             # shoot_ray stores its flipped angle (REF/launch_rays.py:251,318)
+    else:
+        ode = launch_angles
+        stored = -launch_angles  # REF/launch_rays.py:180
+    out = _shoot_ode_angles(source_depth, source_range, ode, receiver_range, num_range_save,
+                            environment, rtol, terminate_backwards, flatearth, device=device)
+    _report_drops(out["status"], debug)
+    keep = out["status"] == 0
+    S = len(out["r"])
+    M = int(keep.sum())
+    rs = np.tile(out["r"], (M, 1)) if M * S <= 20_000_000 else np.broadcast_to(out["r"], (M, S))
+    if keep.all():
+        T, Z, P = out["T"], out["z"], out["p"]
+    else:
+        T, Z, P = out["T"][keep], out["z"][keep], out["p"][keep]
+    np.negative(Z, out=Z)  # stored convention z -> -z, p -> -p (REF/ray_objects.py:51-52)
+    np.negative(P, out=P)
+    return RayFan.from_arrays(stored[keep], rs, T, Z, P, out["n_bott"][keep].astype(np.int64),
+                              out["n_surf"][keep].astype(np.int64), np.full(M, source_depth))
+
+
+def shoot_ray(source_depth, source_range, launch_angle, receiver_range, num_range_save, environment,
+              rtol=1e-9, terminate_backwards=True, debug=True, flatearth=True, device=0):
+    """Integrate one ray (REF/launch_rays.py:203-322) -> ``Ray`` or ``None`` if it was dropped.
+    ``Ray.launch_angle`` is the negated user angle, as in the reference (Q2)."""
+    launch_angle = -launch_angle
+    out = _shoot_ode_angles(source_depth, source_range, [launch_angle], receiver_range,
+                            num_range_save, environment, rtol, terminate_backwards, flatearth,
+                            device=device)
+    _report_drops(out["status"], debug)
+    if out["status"][0] != 0:
+        return None
+    y = np.stack([out["T"][0], out["z"][0], out["p"][0]])
+    return Ray(out["r"], y, int(out["n_bott"][0]), int(out["n_surf"][0]), launch_angle, source_depth)
+
+
+__all__ = ["shoot_rays", "shoot_ray", "_unpack_envi"]

@@ -1,0 +1,220 @@
+"""Result containers with pygenray's layout and sign convention.
+
+Mirrors ``pygenray.ray_objects`` (REF = /root/reference/src/pygenray): ``Ray``
+(REF/ray_objects.py:7-59), ``RayFan`` (REF/ray_objects.py:75-155, 262-430) and ``EigenRays``
+(REF/ray_objects.py:433-548).  Stored convention: ``z = -z_ode``, ``p = -p_ode`` (Q3).
+``RayFan.from_arrays`` builds a fan straight from the SoA buffers the HIP path returns,
+without materialising per-ray Python objects.
+"""
+import numpy as np
+
+
+class Ray:
+    """Single ray (REF/ray_objects.py:7-59).  ``y`` is ODE-convention [T; z; p] of shape (3, S)."""
+
+    def __init__(self, r, y, n_bottom, n_surface, launch_angle=None, source_depth=None):
+        self.r = r
+        self.t = y[0, :]
+        self.z = -y[1, :]  # negative-z storage convention
+        self.p = -y[2, :]
+        self.n_bottom = n_bottom
+        self.n_surface = n_surface
+        if launch_angle is not None:
+            self.launch_angle = launch_angle
+        if source_depth is not None:
+            self.source_depth = source_depth
+
+    def plot(self, **kwargs):
+        from matplotlib import pyplot as plt
+        plt.plot(self.r, self.z, **kwargs)
+        plt.xlabel("time [s]")
+        plt.ylabel("depth [m]")
+        plt.ylim([self.z.min(), self.z.max()])
+
+
+class RayFan:
+    """Ray fan (REF/ray_objects.py:75-136): ``thetas (M,)``, ``rs/ts/zs/ps (M, S)``,
+    ``n_botts/n_surfs/source_depths (M,)``, ``ray_ids (M,)``."""
+
+    def __init__(self, Rays):
+        self.thetas = np.array([r.launch_angle for r in Rays])
+        self.rs = np.array([r.r for r in Rays])
+        self.ts = np.array([r.t for r in Rays])
+        self.zs = np.array([r.z for r in Rays])
+        self.ps = np.array([r.p for r in Rays])
+        self.n_botts = np.array([r.n_bottom for r in Rays])
+        self.n_surfs = np.array([r.n_surface for r in Rays])
+        self.source_depths = np.array([r.source_depth for r in Rays])
+        self.compute_rayids()
+
+    @classmethod
+    def from_arrays(cls, thetas, rs, ts, zs, ps, n_botts, n_surfs, source_depths):
+        """Stored-convention arrays in, no copies of the (M, S) blocks."""
+        self = cls.__new__(cls)
+        self.thetas = np.asarray(thetas)
+        self.rs, self.ts, self.zs, self.ps = rs, ts, zs, ps
+        self.n_botts = np.asarray(n_botts)
+        self.n_surfs = np.asarray(n_surfs)
+        self.source_depths = np.asarray(source_depths)
+        self.compute_rayids()
+        return self
+
+    def compute_rayids(self):
+        """Ray IDs: number of sign changes of p times sign(theta), 'b' suffix when the ray
+        touched a boundary (REF/ray_objects.py:138-155)."""
+        if len(self.thetas) == 0:
+            self.ray_ids = np.array([], dtype=str)
+            return
+        ray_ids = np.sum(np.diff(np.sign(self.ps)) != 0, axis=1) * (np.sign(self.thetas))
+        b_mask = (self.n_botts == 0) & (self.n_surfs == 0)
+        self.ray_ids = np.array([str(i) if b else f"{i}b" for i, b in zip(ray_ids, b_mask)])
+
+    def __len__(self):
+        return len(self.thetas)
+
+    def _ray(self, i):
+        # REF/ray_objects.py:385-393: re-negate so Ray() flips back to the stored convention
+        return Ray(r=self.rs[i], y=np.array([self.ts[i], -self.zs[i], -self.ps[i]]),
+                   n_bottom=self.n_botts[i], n_surface=self.n_surfs[i],
+                   launch_angle=self.thetas[i], source_depth=self.source_depths[i])
+
+    def __getitem__(self, key):
+        """int -> Ray; slice / index array / boolean mask -> RayFan (REF/ray_objects.py:358-430)."""
+        if isinstance(key, (int, np.integer)):
+            key = int(key)
+            if key < 0:
+                key = len(self.thetas) + key
+            if key < 0 or key >= len(self.thetas):
+                raise IndexError(
+                    f"Index {key} is out of bounds for RayFan with {len(self.thetas)} rays")
+            return self._ray(key)
+        if isinstance(key, slice):
+            idx = np.arange(len(self.thetas))[key]
+        else:
+            idx = np.asarray(key)
+            if idx.dtype == bool:
+                idx = np.where(idx)[0]
+        if idx.ndim == 0:
+            idx = idx.reshape(1)
+        elif idx.ndim != 1:
+            raise ValueError("Invalid indexing array shape")
+        return RayFan.from_arrays(self.thetas[idx], self.rs[idx], self.ts[idx], self.zs[idx],
+                                  self.ps[idx], self.n_botts[idx], self.n_surfs[idx],
+                                  self.source_depths[idx])
+
+    def __add__(self, other):
+        """Concatenate along the launch-angle dimension (REF/ray_objects.py:290-345).  Unlike
+        the reference (whose ``__add__`` rebuilds Rays without re-negating and so flips the
+        sign of zs/ps, Q3), the stored convention is preserved."""
+        if not isinstance(other, RayFan):
+            raise TypeError("Can only add RayFan objects together")
+        if not np.array_equal(self.rs[0], other.rs[0]):
+            raise ValueError("Range arrays (rs) must be equivalent for concatenation")
+        cat = np.concatenate
+        return RayFan.from_arrays(cat([self.thetas, other.thetas]), cat([self.rs, other.rs]),
+                                  cat([self.ts, other.ts]), cat([self.zs, other.zs]),
+                                  cat([self.ps, other.ps]), cat([self.n_botts, other.n_botts]),
+                                  cat([self.n_surfs, other.n_surfs]),
+                                  cat([self.source_depths, other.source_depths]))
+
+    def save_mat(self, filename):
+        """.mat export with the reference's schema (REF/ray_objects.py:262-288)."""
+        from scipy import io
+        io.savemat(filename, {"rayfan": {
+            "thetas": self.thetas, "xs": self.rs, "ts": self.ts, "zs": self.zs, "ps": self.ps,
+            "n_botts": self.n_botts, "n_surfs": self.n_surfs, "source_depths": self.source_depths}})
+
+    # ---- plots (REF/ray_objects.py:157-260) ----
+    def plot_time_front(self, include_lines=False, range_idx=-1, add_colorbar=True, ray_id=False,
+                        **kwargs):
+        from matplotlib import pyplot as plt
+        if include_lines:
+            plt.plot(self.ts[:, range_idx], self.zs[:, range_idx], c="#aaaaaa", lw=0.5, zorder=5)
+        kw = {"c": self.thetas, "cmap": "viridis", "s": 2, "lw": 0, "zorder": 6}
+        kw.update(kwargs)
+        if ray_id:
+            cats = np.unique(self.ray_ids)
+            colors = plt.cm.tab20(np.linspace(0, 1, len(cats)))
+            lut = dict(zip(cats, colors))
+            kw.update({"c": [lut[c] for c in self.ray_ids]})
+            kw.pop("cmap", None)
+            add_colorbar = False
+        plt.scatter(self.ts[:, range_idx], self.zs[:, range_idx], **kw)
+        if add_colorbar:
+            plt.colorbar(label="launch angle [°]")
+        plt.xlabel("time [s]")
+        plt.ylabel("depth [m]")
+
+    def plot_ray_fan(self, **kwargs):
+        from matplotlib import pyplot as plt
+        a = 10 * 1 / max(len(self.thetas), 1)
+        kw = {"c": "k", "lw": 1, "alpha": 1 if (a > 1 or a < 0) else a}
+        kw.update(kwargs)
+        plt.plot(self.rs.T, self.zs.T, **kw)
+
+    def plot_depth_v_angle(self, include_line=False, **kwargs):
+        from matplotlib import pyplot as plt
+        kw = {"c": self.thetas, "cmap": "viridis", "s": 2, "lw": 0, "zorder": 6}
+        kw.update(kwargs)
+        if include_line:
+            plt.plot(self.thetas, self.zs[:, -1], c="#aaaaaa", lw=0.5)
+        plt.scatter(self.thetas, self.zs[:, -1], **kw)
+        plt.xlabel("launch angle [°]")
+        plt.ylabel("depth [m]")
+
+
+class EigenRays:
+    """Eigenrays per receiver depth (REF/ray_objects.py:433-548)."""
+
+    def __init__(self, receiver_depths, eigenray_dict, environment, num_eigenrays,
+                 num_eigenrays_found, failed_eray_theta_brackets):
+        from .host_physics import ray_angle
+        from .environment import OceanEnvironment2D
+        self.receiver_depths = receiver_depths
+        self.rs, self.ts, self.zs, self.ps = {}, {}, {}, {}
+        self.received_angles, self.launch_angles = {}, {}
+        self.n_botts, self.n_surfs = {}, {}
+        self.ray_id, self.ray_id_int = {}, {}
+        self.num_eigenrays = num_eigenrays
+        self.num_eigenrays_found = num_eigenrays_found
+        self.failed_eray_theta_brackets = failed_eray_theta_brackets
+        cin, rin, zin = OceanEnvironment2D._range_depth(environment.sound_speed)
+        for ridx in range(len(receiver_depths)):
+            fan = eigenray_dict[ridx]
+            if not isinstance(fan, RayFan):
+                fan = RayFan(fan)
+            self.rs[ridx], self.ts[ridx], self.zs[ridx], self.ps[ridx] = fan.rs, fan.ts, fan.zs, fan.ps
+            self.n_botts[ridx], self.n_surfs[ridx] = fan.n_botts, fan.n_surfs
+            ang, ids, ids_int = [], [], []
+            for k in range(len(fan)):
+                # REF/ray_objects.py:521-534: received angle from the stored (negative-z)
+                # state and the non-flat-earth table, exactly as the reference does (Q13)
+                y_last = np.array([fan.ts[k, -1], fan.zs[k, -1], fan.ps[k, -1]])
+                with np.errstate(invalid="ignore"):
+                    theta, _ = ray_angle(fan.rs[k, -1], y_last, cin, rin, zin)
+                ang.append(theta)
+                rid = np.sum(np.diff(np.sign(fan.ps[k, :])) != 0) * np.sign(fan.thetas[k])
+                flag = "" if (fan.n_botts[k] == 0 and fan.n_surfs[k] == 0) else "b"
+                ids.append(f"{rid}{flag}")
+                ids_int.append(int(rid))
+            self.received_angles[ridx] = np.array(ang)
+            self.launch_angles[ridx] = fan.thetas
+            self.ray_id[ridx] = np.array(ids)
+            self.ray_id_int[ridx] = np.array(ids_int)
+
+    def plot_angle_time(self, ridxs=None, **kwargs):
+        from matplotlib import pyplot as plt
+        for ridx in (ridxs if ridxs is not None else list(self.received_angles.keys())):
+            plt.scatter(self.ts[ridx][:, -1], self.received_angles[ridx], **kwargs)
+        plt.xlabel("time [s]")
+        plt.ylabel("received angle [°]")
+
+    def plot(self, ridxs=[0], **kwargs):
+        from matplotlib import pyplot as plt
+        for ridx in ridxs:
+            plt.plot(self.rs[ridx].T, self.zs[ridx].T, **kwargs)
+        plt.xlabel("range [m]")
+        plt.ylabel("depth [m]")
+
+
+__all__ = ["Ray", "RayFan", "EigenRays"]

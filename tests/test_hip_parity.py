@@ -1,0 +1,280 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and the golden vectors.
+
+Everything here needs a real MI355X: run with ``pytest -m gpu``.  The oracle is only the
+checker; the thing under test is ``libpgr_hip.so`` reached through ctypes (pygenray_amd._lib)
+and the drop-in API on top of it.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from helpers import (load, env_from, tiled_env, munk, munk_arrays, y0_for, assert_fan_parity,
+                     oracle_selfnoise, XI_MAX)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from pygenray_amd import _lib
+    _lib.load()
+    assert _lib.device_count() >= 1
+    return _lib
+
+
+def gpu_vs_oracle(lib, arrs, y0, x0, x1, S, label, abs_floor=None, scales=None, **kw):
+    env = lib.EnvHandle(*arrs)
+    g = env.shoot_fan(y0, x0, x1, S, **kw)
+    o = oracle.shoot_fan(*arrs, y0, x0, x1, S, **kw)
+    noise = oracle_selfnoise(oracle, arrs, y0, x0, x1, S, **kw)
+    if scales is None:
+        scales = (float(arrs[3][-1]), max(float(np.nanmax(np.where(np.isnan(o["T"]), 0, o["T"]))), 1e-9), 1 / 1500.0)
+    worst = assert_fan_parity(g, o, noise_runs=noise, scales=scales, label=label, abs_floor=abs_floor)
+    ok = o["status"] == 0
+    dsteps = np.abs(g["n_steps"][ok].astype(np.int64) - o["n_steps"][ok])
+    assert np.all(dsteps <= np.maximum(2, 0.04 * o["n_steps"][ok])), dsteps.max()
+    # the last column is the exact final state and equals end_state
+    assert np.array_equal(g["end"][ok, 1], g["z"][ok, -1])
+    env.close()
+    return g, o, worst
+
+
+# ------------------------------------------------------------------ unit level: a1-a8 on the device
+def test_device_unit_vectors(lib):
+    g = load("g7_unit_vectors.npz")
+    nb = len(g["depths"])
+    env = lib.EnvHandle(g["cin"], g["cpin"], g["rin"], g["zin"], g["depths"], g["depth_ranges"], np.zeros(nb))
+    out = env.eval_points(g["xs"], g["ys"])
+    np.testing.assert_allclose(out[:, 0:3], g["derivs"], rtol=1e-14, atol=0)
+    np.testing.assert_allclose(out[:, 3], g["bilinear"], rtol=4e-16, atol=0)
+    nan = np.isnan(g["angle"][:, 0])
+    assert np.array_equal(np.isnan(out[:, 4]), nan)
+    np.testing.assert_allclose(out[~nan, 4], g["angle"][~nan, 0], rtol=1e-13, atol=1e-12)
+    np.testing.assert_array_equal(out[:, 5:9], g["events"])
+    np.testing.assert_allclose(out[:, 9], g["linear"], rtol=4e-16, atol=0)
+    # extrapolation quirk Q4 on the device
+    gr = np.array([0.0, 1, 2, 3])
+    v = np.arange(16.0).reshape(4, 4)
+    e2 = lib.EnvHandle(v, v, gr, gr, np.zeros(4), gr, np.zeros(4))
+    o2 = e2.eval_points(np.array([4.0, 0.5]), np.array([[0, 0.0, 0], [0, 0.5, 0]]))
+    assert o2[0, 3] == oracle.bilinear(4.0, 0.0, gr, gr, v) and o2[1, 3] == oracle.bilinear(0.5, 0.5, gr, gr, v)
+
+
+# ------------------------------------------------------------------ golden fans (reference outputs)
+def golden_check(lib, g, arrs, x0, x1, S, prefix="", label="", abs_floor=None, **kw):
+    env = lib.EnvHandle(*arrs)
+    out = env.shoot_fan(g[prefix + "y0"], x0, x1, S, **kw)
+    o = oracle.shoot_fan(*arrs, g[prefix + "y0"], x0, x1, S, **kw)  # for xi + noise only
+    ok = g[prefix + "ok"].astype(bool)
+    ref = dict(T=g[prefix + "T"], z=g[prefix + "z"], p=g[prefix + "p"], n_bott=g[prefix + "n_bott"],
+               n_surf=g[prefix + "n_surf"], status=np.where(ok, 0, -1), xi=o["xi"])
+    test = dict(out)
+    test["status"] = np.where(out["status"] == 0, 0, -1)
+    noise = oracle_selfnoise(oracle, arrs, g[prefix + "y0"], x0, x1, S, **kw)
+    for n in noise:
+        n["status"] = np.where(n["status"] == 0, 0, -1)
+    assert_fan_parity(test, ref, noise_runs=noise,
+                      scales=(float(arrs[3][-1]), float(np.nanmax(ref["T"])), 1 / 1500.0), label=label,
+                      abs_floor=abs_floor)
+    env.close()
+    return out
+
+
+def test_golden_munk_100km(lib):
+    g = load("g2_munk_100km.npz")
+    out = golden_check(lib, g, tiled_env(g), 0.0, 100e3, 101, label="g2")
+    quiet = (g["n_bott"] + g["n_surf"]) == 0
+    assert np.abs(out["z"][quiet] - g["z"][quiet]).max() / 5000 < 1e-8
+    assert np.abs(out["T"][quiet] - g["T"][quiet]).max() / 67.0 < 1e-8
+    assert np.array_equal(out["n_steps"][quiet], g["n_steps"][quiet])
+
+
+def test_golden_munk_1000km(lib):
+    g = load("g3_munk_1000km.npz")
+    out = golden_check(lib, g, tiled_env(g), 0.0, 1000e3, 101, label="g3")
+    end = out["end"]
+    gend = np.stack([g["T"][:, -1], g["z"][:, -1], g["p"][:, -1]], 1)
+    tol = np.maximum(20 * g["selfnoise_end"], 1e-8 * np.array([670.0, 6000.0, 1 / 1500.0]))
+    assert np.all(np.abs(end - gend) <= tol)
+
+
+def test_golden_range_dependent_and_mirrored(lib):
+    g = load("g4_range_dependent.npz")
+    arrs = env_from(g)
+    floor = dict(T=1e-6, z=1e-2, p=1e-7)  # the reference's own tolerances on this coarse grid
+    golden_check(lib, g, arrs, 10e3, 90e3, 81, prefix="fwd_", label="g4 fwd", abs_floor=floor)
+    arrs_m = [np.ascontiguousarray(arrs[0][::-1]), np.ascontiguousarray(arrs[1][::-1]), -arrs[2][::-1],
+              arrs[3], np.ascontiguousarray(arrs[4][::-1]), -arrs[5][::-1], -arrs[6][::-1]]
+    golden_check(lib, g, arrs_m, -60e3, -10e3, 80, prefix="bwd_", label="g4 bwd", abs_floor=floor)
+
+
+def test_golden_config2_subset(lib):
+    g = load("g4_config2_subset.npz")
+    arrs = munk_arrays(float(g["r_max"]), nr=int(g["nr"]), sofar_slope=float(g["sofar_slope"]))
+    golden_check(lib, g, arrs, 0.0, 1000e3, 101, label="g4 config2")
+
+
+def test_golden_const_c_steep_linear_flatearth(lib):
+    g = load("g5_const_c.npz")
+    golden_check(lib, g, env_from(g), 0.0, 30e3, 60, label="const c")
+    g = load("g5_const_c_steep.npz")
+    golden_check(lib, g, env_from(g), 0.0, 1.5e3, 31, rtol=float(g["rtol"]), label="steep")
+    g = load("g5_flatearth.npz")
+    golden_check(lib, g, env_from(g), 0.0, 100e3, 101, label="flat earth (non-uniform zin)")
+
+
+def test_reference_fixture_through_dropin_api(lib):
+    """The reference's TestMunkRegression (tests/test_physics.py:310-386) run through the
+    drop-in API against the reference's committed fixture."""
+    import pygenray_amd as pr
+    z = np.linspace(0.0, 6000.0, 400)
+    r = np.linspace(0.0, 50e3, 30)
+    ssp = pr.DataArray(np.outer(np.ones(30), pr.munk_ssp(z)), dims=["range", "depth"],
+                       coords={"range": r, "depth": z})
+    bathy = pr.DataArray(np.full(30, 5000.0), dims=["range"], coords={"range": r})
+    env = pr.OceanEnvironment2D(sound_speed=ssp, bathymetry=bathy, flat_earth_transform=False)
+    rf = pr.shoot_rays(1300.0, 0.0, [-8.0, -4.0, 0.0, 4.0, 8.0], 50e3, 50, env, n_processes=1,
+                       debug=False, flatearth=False)
+    ref = load("ref_munk_regression.npz")
+    np.testing.assert_allclose(rf.ts, ref["ts"], atol=5e-6)
+    np.testing.assert_allclose(rf.zs, ref["zs"], atol=0.1)
+    np.testing.assert_allclose(rf.ps, ref["ps"], atol=0.1)
+    np.testing.assert_array_equal(rf.n_botts, ref["n_botts"])
+    np.testing.assert_array_equal(rf.n_surfs, ref["n_surfs"])
+    np.testing.assert_array_equal(rf.thetas, ref["thetas"])
+
+
+# ------------------------------------------------------------------ HIP vs oracle on seeded inputs
+def test_fan_vs_oracle_munk_lds_path(lib):
+    arrs = munk_arrays(200e3)
+    theta = np.linspace(-20, 20, 333)  # ragged: not a multiple of 64
+    y0 = y0_for(oracle, arrs, 1000.0, 0.0, theta)
+    g, o, worst = gpu_vs_oracle(lib, arrs, y0, 0.0, 200e3, 201, "munk 200 km")
+    quiet = (o["n_bott"] + o["n_surf"]) == 0
+    assert np.abs(g["z"][quiet] - o["z"][quiet]).max() / 5000 < 1e-8
+    assert np.array_equal(g["n_steps"][quiet], o["n_steps"][quiet])
+
+
+def test_fan_vs_oracle_range_dependent_sloping_bottom(lib):
+    rng = np.random.default_rng(11)
+    z = np.arange(0, 5500, 2.0)
+    r = np.linspace(0, 150e3, 61)
+    cin = np.array([munk(z, 1300 + 2e-3 * ri) for ri in r]) + rng.normal(0, 0.05, (61, len(z))).cumsum(1) * 0.01
+    cpin = np.gradient(cin, z, axis=1, edge_order=1)
+    br = np.linspace(0, 150e3, 31)
+    depths = 4800 + 300 * np.sin(br / 20e3)
+    ba = np.degrees(np.arctan(np.gradient(depths, br)))
+    arrs = [cin, cpin, r, z, depths, br, ba]
+    y0 = y0_for(oracle, arrs, 700.0, 5e3, np.linspace(-18, 18, 130))
+    g, o, worst = gpu_vs_oracle(lib, arrs, y0, 5e3, 140e3, 136, "range dependent")
+    assert (o["n_bott"] > 0).any() and (o["n_surf"] > 0).any()
+
+
+def test_nonuniform_grids_generic_search_path(lib):
+    rng = np.random.default_rng(2)
+    z = np.sort(np.concatenate([[0.0, 6000.0], rng.uniform(0, 6000, 800)]))
+    r = np.sort(np.concatenate([[0.0, 80e3], rng.uniform(0, 80e3, 25)]))
+    cin = np.array([munk(z, 1300 + 1e-3 * ri) for ri in r])
+    cpin = np.gradient(cin, z, axis=1, edge_order=1)
+    br = np.sort(np.concatenate([[0.0, 80e3], rng.uniform(0, 80e3, 9)]))
+    depths = 4700 + 100 * np.cos(br / 9e3)
+    arrs = [cin, cpin, r, z, depths, br, np.degrees(np.arctan(np.gradient(depths, br)))]
+    env = lib.EnvHandle(*arrs)
+    assert not env.query(1) and not env.query(2)
+    env.close()
+    y0 = y0_for(oracle, arrs, 900.0, 0.0, np.linspace(-15, 15, 70))
+    gpu_vs_oracle(lib, arrs, y0, 0.0, 80e3, 81, "non-uniform grids", abs_floor=dict(T=1e-7, z=1e-3, p=1e-8))
+
+
+def test_dropped_rays_and_statuses(lib):
+    # backward bounce off a wall, bbox exit, near-vertical rays: same statuses as the oracle
+    arrs = munk_arrays(50e3, nr=20, z=np.linspace(0, 6000, 601))
+    arrs[4] = np.where(arrs[2] > 20e3, 1000.0, 5000.0).astype(float)
+    arrs[6] = np.degrees(np.arctan(np.gradient(arrs[4], arrs[5])))
+    y0 = y0_for(oracle, arrs, 500.0, 0.0, [12.0, 0.5, -3.0, 14.0])
+    g, o, _ = gpu_vs_oracle(lib, arrs, y0, 0.0, 50e3, 26, "wall")
+    assert g["status"][0] == 3 and np.all(np.isnan(g["z"][0])) and np.all(np.isnan(g["end"][0]))
+    arrs = munk_arrays(50e3, nr=20, z=np.linspace(0, 3000, 301), bathy=5000.0)
+    y0 = y0_for(oracle, arrs, 500.0, 0.0, [14.0, 2.0])
+    g, o, _ = gpu_vs_oracle(lib, arrs, y0, 0.0, 50e3, 26, "bbox")
+    assert g["status"][0] == 2 and g["status"][1] == 0
+
+
+def test_near_vertical_rays_do_not_crash(lib):
+    """tests/test_physics.py:394-455 of the reference: steep launches must not blow up (Q8)."""
+    import pygenray_amd as pr
+    z = np.linspace(0.0, 5000.0, 200)
+    r = np.linspace(0.0, 100e3, 20)
+    ssp = pr.DataArray(np.full((20, 200), 1500.0), dims=["range", "depth"], coords={"range": r, "depth": z})
+    bathy = pr.DataArray(np.full(20, 4500.0), dims=["range"], coords={"range": r})
+    env = pr.OceanEnvironment2D(ssp, bathy, flat_earth_transform=False)
+    for ang in (-85.0, -89.0):
+        ray = pr.shoot_ray(200.0, 0.0, ang, 2e3, 50, env, rtol=1e-6, flatearth=False, debug=False)
+        assert ray is None or np.all(np.isfinite(ray.z))
+    # exactly vertical / 89.9 deg bounce ~forever: the step guard ends them (status 5), no hang
+    handle = lib.EnvHandle(*pr._unpack_envi(env, flatearth=False))
+    y0 = np.array([[0, 200.0, np.sin(np.radians(a)) / 1500.0] for a in (89.9, 90.0)])
+    out = handle.shoot_fan(y0, 0.0, 10e3, 50, rtol=1e-6, max_steps=20000)
+    assert np.all(np.isin(out["status"], [1, 3, 4, 5]))
+
+
+def test_layouts_and_end_state_only(lib):
+    arrs = munk_arrays(100e3)
+    y0 = y0_for(oracle, arrs, 1000.0, 0.0, np.linspace(-19, 19, 200))
+    env = lib.EnvHandle(*arrs)
+    a = env.shoot_fan(y0, 0.0, 100e3, 64)
+    b = env.shoot_fan(y0, 0.0, 100e3, 64, sample_major=True)
+    c = env.shoot_fan(y0, 0.0, 100e3, 64, save=False)
+    for nm in "Tzp":
+        assert np.array_equal(a[nm], b[nm].T)
+    assert np.array_equal(a["end"], c["end"]) and np.array_equal(a["n_steps"], c["n_steps"])
+    assert c["T"] is None
+    # every workgroup shape gives identical results (rays are independent)
+    for w in (1, 3, 8):
+        lib.set_waves_per_block(w)
+        d = env.shoot_fan(y0, 0.0, 100e3, 64)
+        assert np.array_equal(a["z"], d["z"]) and np.array_equal(a["status"], d["status"])
+    lib.set_waves_per_block(0)
+    # no sentinel survives: every sample of an OK ray is written
+    assert np.all(np.isfinite(a["T"][a["status"] == 0]))
+    # empty fan and argument errors
+    e = env.shoot_fan(np.zeros((0, 3)), 0.0, 100e3, 8)
+    assert e["status"].shape == (0,)
+    with pytest.raises(lib.PgrError):
+        env.shoot_fan(y0, 100e3, 0.0, 8)
+    with pytest.raises(lib.PgrError):
+        lib.EnvHandle(arrs[0], arrs[1], arrs[2][::-1].copy(), arrs[3], arrs[4], arrs[5], arrs[6])
+    with pytest.raises(lib.PgrError):
+        lib.EnvHandle(arrs[0], arrs[1], arrs[2], arrs[3], arrs[4][:3], arrs[5][:3], arrs[6][:3])
+
+
+# ------------------------------------------------------------------ full size: size-independent properties
+def test_full_size_config1_properties(lib):
+    """BASELINE configs[1] at full size (1e5 rays, 1000 km): the oracle cannot run this in
+    seconds, so check properties: (i) a strided 1/500 subset equals the oracle within the
+    parity policy, (ii) determinism, (iii) the range-independent Hamiltonian
+    sqrt(1/c^2 - p^2) is conserved along every ray, (iv) up/down symmetry of step counts is
+    not required but bounce counts are monotone in |angle| at the fan edges."""
+    arrs = munk_arrays(1000e3)
+    theta = np.linspace(-20, 20, 100_000)
+    y0 = y0_for(oracle, arrs, 1000.0, 0.0, -theta)
+    env = lib.EnvHandle(*arrs)
+    a = env.shoot_fan(y0, 0.0, 1000e3, 101)
+    b = env.shoot_fan(y0, 0.0, 1000e3, 101)
+    assert np.array_equal(a["end"], b["end"], equal_nan=True) and np.array_equal(a["n_steps"], b["n_steps"])
+    ok = a["status"] == 0
+    assert ok.mean() > 0.999
+    sub = np.arange(0, 100_000, 500)
+    o = oracle.shoot_fan(*arrs, y0[sub], 0.0, 1000e3, 101)
+    noise = oracle_selfnoise(oracle, arrs, y0[sub], 0.0, 1000e3, 101)
+    gsub = {k: (v[sub] if isinstance(v, np.ndarray) and v.shape[:1] == (100_000,) else v) for k, v in a.items()}
+    assert_fan_parity(gsub, o, noise_runs=noise, scales=(5000.0, 680.0, 1 / 1500.0), label="config1 subset")
+    # Hamiltonian at the end state vs at the source
+    zc = np.clip(a["end"][ok, 1], 0, 5998.999)
+    c_end = np.interp(zc, arrs[3], arrs[0][0])
+    H_end = np.sqrt(np.maximum(1 / c_end**2 - a["end"][ok, 2]**2, 0))
+    c0 = oracle.bilinear(0.0, 1000.0, arrs[2], arrs[3], arrs[0])
+    H0 = np.sqrt(1 / c0**2 - y0[ok, 2]**2)
+    assert np.abs(H_end / H0 - 1).max() < 5e-6
+    total = int(a["n_steps"][ok].sum())
+    assert 1.2e8 < total < 1.7e8

@@ -1,0 +1,281 @@
+"""Host-side logic that needs no GPU: the environment front end, result containers, the
+C-ABI library's exported symbols, loud failure without the extension, and the multi-GPU
+sharding / all-gather path under gloo (world_size 2, CPU)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import pygenray_amd as pr
+from pygenray_amd import OceanEnvironment2D, DataArray, Ray, RayFan, munk_ssp, eflat, eflatinv
+from pygenray_amd.environment import _unpack_envi, _mirror_envi_arrays
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---------------------------------------------------------------- environment (REF tests/test_environment.py)
+def test_munk_ssp():
+    z = np.arange(0, 6000, 1)
+    c = munk_ssp(z, sofar_depth=1300.0)
+    assert c.shape == z.shape and z[np.argmin(c)] == pytest.approx(1300.0, abs=2.0)
+    assert munk_ssp(np.array([1300.0]))[0] == pytest.approx(1500.0, abs=5.0)
+
+
+def test_environment_defaults_and_attributes():
+    env = OceanEnvironment2D()
+    for attr in ("sound_speed", "bathymetry", "dcdz", "bottom_angle", "bottom_angle_interp",
+                 "sound_speed_fe", "bathymetry_fe"):
+        assert hasattr(env, attr)
+    assert env.sound_speed.ndim == 2 and set(env.sound_speed.dims) == {"range", "depth"}
+    env2 = OceanEnvironment2D(flat_earth_transform=False)
+    assert not hasattr(env2, "sound_speed_fe") and not hasattr(env2, "bathymetry_fe")
+    # Q11: the default bathymetry is a 4500 -> 4900 m slope; Q10: slope angle in degrees
+    assert env.bathymetry.values[0] == 4500 and env.bathymetry.values[-1] == 4900
+    assert env.bottom_angle[0] == pytest.approx(np.degrees(np.arctan(400 / 100e3)))
+    assert float(env.bottom_angle_interp(50e3)) == pytest.approx(env.bottom_angle[50], rel=1e-6)
+
+
+def test_environment_custom_and_validation():
+    z = np.arange(0.0, 3000.0, 10.0)
+    ssp1 = DataArray(munk_ssp(z), dims=["depth"], coords={"depth": z})
+    bathy = DataArray(np.ones(20) * 4000.0, dims=["range"], coords={"range": np.linspace(0, 50e3, 20)})
+    env = OceanEnvironment2D(sound_speed=ssp1, bathymetry=bathy, flat_earth_transform=False)
+    assert env.sound_speed.ndim == 1
+    np.testing.assert_array_equal(env.bathymetry.values, np.ones(20) * 4000.0)
+    with pytest.raises(TypeError):
+        OceanEnvironment2D(sound_speed=np.ones(100))
+    with pytest.raises(TypeError):
+        OceanEnvironment2D(bathymetry=np.ones(50))
+    with pytest.raises(ValueError):
+        OceanEnvironment2D(sound_speed=DataArray(np.ones((5, 10, 20)), dims=["range", "depth", "extra"]))
+    with pytest.raises(ValueError):
+        OceanEnvironment2D(sound_speed=DataArray(np.ones(50), dims=["range"], coords={"range": np.arange(50)}))
+    with pytest.raises(ValueError):
+        OceanEnvironment2D(sound_speed=DataArray(np.ones((10, 20)), dims=["depth", "extra"],
+                                                 coords={"depth": np.arange(10), "extra": np.arange(20)}))
+    with pytest.raises(ValueError):
+        OceanEnvironment2D(bathymetry=DataArray(np.ones(50), dims=["depth"], coords={"depth": np.arange(50)}))
+
+
+def test_eflat_roundtrip():
+    dep = np.array([100.0, 500.0, 1000.0, 2000.0, 4000.0])
+    cs = np.array([1500.0, 1490.0, 1480.0, 1510.0, 1520.0])
+    depf, csf = eflat(dep, 35.0, cs)
+    assert np.all(depf > dep)
+    dep_rec, cs_rec = eflatinv(depf, np.array([35.0]), csf)
+    np.testing.assert_allclose(dep_rec, dep, atol=1e-3)
+    np.testing.assert_allclose(cs_rec, cs, rtol=1e-6)
+
+
+def test_unpack_matches_reference_tables(golden_dir):
+    """_unpack_envi reproduces the 7 arrays the reference's _unpack_envi produced (golden g1:
+    Munk nz=400; g5: flat-earth tables with the default sloping bathymetry)."""
+    g = np.load(os.path.join(golden_dir, "g1_fixture_case.npz"))
+    z = np.linspace(0.0, 6000.0, 400)
+    r = np.linspace(0.0, 50e3, 30)
+    env = OceanEnvironment2D(DataArray(np.outer(np.ones(30), munk_ssp(z)), dims=["range", "depth"],
+                                       coords={"range": r, "depth": z}),
+                             DataArray(np.full(30, 5000.0), dims=["range"], coords={"range": r}),
+                             flat_earth_transform=False)
+    got = _unpack_envi(env, flatearth=False)
+    for a, k in zip(got, ["cin", "cpin", "rin", "zin", "depths", "depth_ranges", "bottom_angles"]):
+        np.testing.assert_array_equal(a, g["env_" + k])
+    g = np.load(os.path.join(golden_dir, "g5_flatearth.npz"))
+    zf = np.arange(0, 6000, 4.0)
+    rf = np.linspace(0.0, 100e3, 100)
+    env = OceanEnvironment2D(DataArray(np.outer(np.ones(100), munk_ssp(zf)), dims=["range", "depth"],
+                                       coords={"range": rf, "depth": zf}),
+                             DataArray(np.linspace(4500, 4900, 100), dims=["range"], coords={"range": rf}),
+                             lat=35.0, flat_earth_transform=True)
+    got = _unpack_envi(env, flatearth=True)
+    for a, k in zip(got, ["cin", "cpin", "rin", "zin", "depths", "depth_ranges", "bottom_angles"]):
+        np.testing.assert_allclose(a, g["env_" + k], rtol=1e-15, atol=0)
+    # depth-major input is normalised to (range, depth)
+    env_t = OceanEnvironment2D(DataArray(np.outer(munk_ssp(zf), np.ones(100)), dims=["depth", "range"],
+                                         coords={"range": rf, "depth": zf}), flat_earth_transform=False)
+    assert _unpack_envi(env_t, flatearth=False)[0].shape == (100, len(zf))
+    with pytest.raises(Exception, match="Flat earth"):
+        _unpack_envi(OceanEnvironment2D(flat_earth_transform=False), flatearth=True)
+
+
+def test_mirror_arrays():
+    cin = np.arange(12.0).reshape(3, 4)
+    out = _mirror_envi_arrays(cin, cin + 1, np.array([0.0, 1, 3]), np.array([5.0, 6, 7]),
+                              np.array([0.0, 2, 3]), np.array([1.0, -2, 3]))
+    np.testing.assert_array_equal(out[0], cin[::-1])
+    np.testing.assert_array_equal(out[2], [-3.0, -1, 0])
+    np.testing.assert_array_equal(out[3], [7.0, 6, 5])
+    np.testing.assert_array_equal(out[4], [-3.0, -2, 0])
+    np.testing.assert_array_equal(out[5], [-3.0, 2, -1])
+
+
+# ---------------------------------------------------------------- containers (REF tests/test_ray_objects.py)
+def _make_rays(M=3, N=10, R=10000.0):
+    rays = []
+    for i in range(M):
+        r = np.linspace(0.0, R, N)
+        theta = float(-5 + i * 5)
+        y = np.vstack([r / 1500.0, np.linspace(100.0 + i * 50, 200.0 + i * 50, N),
+                       np.ones(N) * np.sin(np.radians(abs(theta) + 1e-3)) / 1500.0])
+        rays.append(Ray(r=r, y=y, n_bottom=i % 2, n_surface=0, launch_angle=theta, source_depth=100.0 + i * 50))
+    return rays
+
+
+def test_ray_sign_convention_and_optionals():
+    r = np.linspace(0, 1e4, 10)
+    y = np.vstack([r / 1500.0, np.linspace(100, 200, 10), np.ones(10) * 1e-4])
+    ray = Ray(r=r, y=y, n_bottom=3, n_surface=1, launch_angle=-15.0, source_depth=250.0)
+    np.testing.assert_array_equal(ray.z, -y[1])
+    np.testing.assert_array_equal(ray.p, -y[2])
+    assert (ray.n_bottom, ray.n_surface, ray.launch_angle, ray.source_depth) == (3, 1, -15.0, 250.0)
+    bare = Ray(r=r, y=y, n_bottom=0, n_surface=0)
+    assert not hasattr(bare, "launch_angle") and not hasattr(bare, "source_depth")
+
+
+def test_rayfan_shapes_slicing_add_mat(tmp_path):
+    rf = RayFan(_make_rays())
+    assert rf.thetas.shape == (3,) and rf.rs.shape == rf.ts.shape == rf.zs.shape == rf.ps.shape == (3, 10)
+    assert len(rf) == 3 and rf.ray_ids.shape == (3,)
+    assert list(rf.ray_ids) == ["-0.0", "0.0b", "0.0"]
+    one = rf[1]
+    assert isinstance(one, Ray) and one.launch_angle == 0.0
+    np.testing.assert_array_equal(one.z, rf.zs[1])  # sign convention survives indexing (Q3)
+    assert isinstance(rf[-1], Ray)
+    with pytest.raises(IndexError):
+        rf[3]
+    sub = rf[0:2]
+    assert isinstance(sub, RayFan) and len(sub) == 2
+    np.testing.assert_array_equal(sub.zs, rf.zs[0:2])
+    assert len(rf[np.array([True, False, True])]) == 2 and len(rf[[0, 2]]) == 2
+    both = rf + RayFan(_make_rays(M=2))
+    assert len(both) == 5
+    np.testing.assert_array_equal(both.rs[0], rf.rs[0])
+    np.testing.assert_array_equal(both.zs[:3], rf.zs)
+    with pytest.raises(TypeError):
+        rf + 1
+    with pytest.raises(ValueError):
+        rf + RayFan(_make_rays(R=5000.0))
+    import scipy.io
+    rf.save_mat(str(tmp_path / "fan.mat"))
+    m = scipy.io.loadmat(str(tmp_path / "fan.mat"))["rayfan"]
+    for key in ("thetas", "xs", "ts", "zs", "ps", "n_botts", "n_surfs", "source_depths"):
+        assert key in m.dtype.names
+    np.testing.assert_allclose(m["zs"][0, 0], rf.zs)
+
+
+def test_rayfan_from_arrays_equals_list_constructor():
+    rays = _make_rays(M=4)
+    a = RayFan(rays)
+    b = RayFan.from_arrays(a.thetas, a.rs, a.ts, a.zs, a.ps, a.n_botts, a.n_surfs, a.source_depths)
+    for k in ("thetas", "rs", "ts", "zs", "ps", "n_botts", "n_surfs", "source_depths", "ray_ids"):
+        np.testing.assert_array_equal(getattr(a, k), getattr(b, k))
+
+
+def test_plots_smoke():
+    import matplotlib
+    matplotlib.use("Agg")
+    from matplotlib import pyplot as plt
+    rf = RayFan(_make_rays())
+    plt.figure(); rf.plot_ray_fan(); rf.plot_time_front(); rf.plot_time_front(ray_id=True, include_lines=True)
+    rf.plot_depth_v_angle(include_line=True); rf[0].plot()
+    OceanEnvironment2D().plot()
+    plt.close("all")
+
+
+# ---------------------------------------------------------------- the C ABI library
+def test_library_exports_every_declared_symbol():
+    from pygenray_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "pgr.h")).read()
+    declared = set(re.findall(r"\b(pgr_[a-z_]+)\s*\(", hdr))
+    declared -= {"pgr_shoot_fan_"}
+    assert {"pgr_env_create", "pgr_shoot_fan", "pgr_shoot_fan_device", "pgr_last_error"} <= declared
+    path = _lib.build()  # hipcc cross-compiles gfx950 without a GPU
+    L = ctypes.CDLL(path)
+    for sym in sorted(declared):
+        assert hasattr(L, sym), sym
+    # the code object is gfx950 only
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", path], capture_output=True, text=True)
+    if out.returncode == 0 and "amdgcn" in out.stdout:
+        assert "gfx950" in out.stdout
+
+
+def test_no_cpu_fallback_and_oracle_not_imported_by_product(tmp_path):
+    """The product never imports oracle/, and fails loudly when the HIP library is missing."""
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import pygenray_amd, numpy as np\n"
+        "from pygenray_amd import _lib\n"
+        "assert 'oracle' not in sys.modules\n"
+        "_lib.LIB_PATH = %r\n"
+        "try:\n"
+        "    pygenray_amd.shoot_ray(1000., 0., 1., 1e4, 5, pygenray_amd.OceanEnvironment2D(), debug=False)\n"
+        "except _lib.PgrError as e:\n"
+        "    assert 'no CPU fallback' in str(e); print('LOUD')\n"
+    ) % (ROOT, str(tmp_path / "missing.so"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert "LOUD" in out.stdout, out.stderr
+    for fn in os.listdir(os.path.join(ROOT, "pygenray_amd")):
+        if fn.endswith(".py"):
+            src = open(os.path.join(ROOT, "pygenray_amd", fn)).read()
+            assert "import oracle" not in src and "from oracle" not in src, fn
+
+
+# ---------------------------------------------------------------- multi-GPU path on gloo (world_size 2)
+_DIST_WORKER = r"""
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np, torch, torch.distributed as dist
+import oracle
+from helpers import munk_arrays, y0_for
+from pygenray_amd.distributed import shoot_fan_sharded, shard_indices, arrival_time_histogram
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=int(sys.argv[1]), world_size=2)
+arrs = munk_arrays(60e3, nr=10, z=np.arange(0, 6000, 5.0))
+theta = np.linspace(-19, 19, 37)     # odd: shards of 19 and 18 rays
+y0 = y0_for(oracle, arrs, 1000.0, 0.0, theta)
+def compute(y0_local):               # the oracle stands in for the HIP fan on this CPU-only box
+    o = oracle.shoot_fan(*arrs, y0_local, 0.0, 60e3, 2)
+    end = np.stack([o["T"][:, -1], o["z"][:, -1], o["p"][:, -1]], 1)
+    return (torch.from_numpy(end), torch.from_numpy(o["n_bott"]), torch.from_numpy(o["n_surf"]),
+            torch.from_numpy(o["status"]))
+end, nb, ns, st = shoot_fan_sharded(compute, y0)
+full = oracle.shoot_fan(*arrs, y0, 0.0, 60e3, 2)
+ref = np.stack([full["T"][:, -1], full["z"][:, -1], full["p"][:, -1]], 1)
+assert end.shape == (37, 3)
+assert np.array_equal(end.numpy(), ref, equal_nan=True), "gathered fan is not in launch-angle order"
+assert np.array_equal(nb.numpy(), full["n_bott"]) and np.array_equal(ns.numpy(), full["n_surf"])
+assert np.array_equal(st.numpy(), full["status"])
+mine = shard_indices(37, dist.get_rank(), 2)
+h_local = arrival_time_histogram(end[mine, 0], st[mine], 16, 39.0, 41.0, reduce=True)
+h_full = arrival_time_histogram(end[:, 0], st, 16, 39.0, 41.0)
+assert torch.equal(h_local, h_full) and h_full.sum() > 0
+dist.barrier(); dist.destroy_process_group()
+print("RANK_OK")
+"""
+
+
+def test_sharded_fan_all_gather_gloo_world2(tmp_path):
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "worker.py"
+    script.write_text(_DIST_WORKER % dict(root=ROOT, port=port))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0 and "RANK_OK" in o, e[-2000:]
+
+
+def test_pack_and_interleave_single_process():
+    import torch
+    from pygenray_amd.distributed import pack_end_records, all_gather_fan, shard_indices
+    end = torch.arange(15, dtype=torch.float64).reshape(5, 3)
+    nb = torch.tensor([1, 2, 3, 4, 5], dtype=torch.int32)
+    buf = pack_end_records(end, nb, nb * 2, nb * 0, 6)
+    assert buf.shape == (6, 5) and buf[5].abs().sum() == 0
+    e2, b2, s2, st2 = all_gather_fan(end, nb, nb * 2, nb * 0, 5)
+    assert torch.equal(e2, end) and torch.equal(b2, nb) and torch.equal(s2, nb * 2)
+    assert list(shard_indices(10, 1, 4)) == [1, 5, 9]
