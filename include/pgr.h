@@ -44,6 +44,14 @@ extern "C" {
 /* flags for pgr_shoot_fan* */
 #define PGR_TERMINATE_BACKWARDS 1u /* REF/launch_rays.py:19,474 (default True) */
 #define PGR_SAMPLE_MAJOR 2u        /* T/z/p laid out [S][N] instead of [N][S] */
+#define PGR_EXACT_BISECTION 4u     /* locate events with brentq's exact ~42-step bisection on the
+                                      +-1 event (SCIPY/ivp.py:51-76) instead of the default
+                                      Newton-on-the-quartic + verified bracket of the same width */
+
+#define PGR_SAVE_LINSPACE 8u       /* (device entry) the caller asserts r_save is exactly
+                                      np.linspace(source_range, receiver_range, S); the kernel then
+                                      recomputes r_save[j] = j*step + start instead of loading it.
+                                      The host entry sets/clears this bit itself after checking. */
 
 typedef struct pgr_env pgr_env; /* opaque: environment tables resident in HBM */
 
@@ -92,8 +100,12 @@ int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, double sourc
                          double* p, double* end_state, int32_t* n_bott, int32_t* n_surf,
                          int32_t* status, int32_t* n_steps, int32_t* n_rej, void* stream);
 
-/* Tuning knob: waves (of 64 rays) per workgroup; 0 = automatic. */
+/* Tuning knobs (process-wide; per-ray results do not depend on them):
+ * waves (of 64 rays) per workgroup, 0 = automatic; and the bounce-service batching: a wave
+ * services its parked (bounced) lanes when `lanes` of them wait or the oldest waited `trips`
+ * step attempts. */
 int pgr_set_waves_per_block(int waves);
+int pgr_set_park(int lanes, int trips);
 
 /* Unit-level device entry points (for parity tests of a1-a8, REF/integration_processes.py):
  * evaluate on the GPU, for M query points (x[k], y[k][3]) given as HOST arrays:

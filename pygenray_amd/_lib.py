@@ -19,6 +19,8 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
 
 PGR_TERMINATE_BACKWARDS = 1
 PGR_SAMPLE_MAJOR = 2
+PGR_EXACT_BISECTION = 4
+PGR_SAVE_LINSPACE = 8
 
 RAY_STATUS = {0: "ok", 1: "vertical", 2: "bbox", 3: "backward", 4: "step_too_small",
               5: "max_steps", 6: "bottom_angle_range", 7: "event_error"}
@@ -79,6 +81,8 @@ def load():
     L.pgr_shoot_fan_device.argtypes = fan_common + [_vp]
     L.pgr_set_waves_per_block.restype = ctypes.c_int
     L.pgr_set_waves_per_block.argtypes = [ctypes.c_int]
+    L.pgr_set_park.restype = ctypes.c_int
+    L.pgr_set_park.argtypes = [ctypes.c_int, ctypes.c_int]
     L.pgr_eval_points.restype = ctypes.c_int
     L.pgr_eval_points.argtypes = [_vp, _dp, _dp, _i64, _dp]
     _lib = L
@@ -145,13 +149,14 @@ class EnvHandle:
 
     # ---- host-pointer entry (NumPy in / NumPy out) ----
     def shoot_fan(self, y0, source_range, receiver_range, num_range_save, rtol=1e-9, atol=1e-6,
-                  terminate_backwards=True, max_steps=1_000_000, save=True, sample_major=False):
+                  terminate_backwards=True, max_steps=1_000_000, save=True, sample_major=False,
+                  exact_bisection=False):
         L = load()
         y0 = _c(y0).reshape(-1, 3)
         N, S = len(y0), int(num_range_save)
         r = np.linspace(source_range, receiver_range, S)
         flags = (PGR_TERMINATE_BACKWARDS if terminate_backwards else 0) | \
-            (PGR_SAMPLE_MAJOR if sample_major else 0)
+            (PGR_SAMPLE_MAJOR if sample_major else 0) | (PGR_EXACT_BISECTION if exact_bisection else 0)
         if save:
             shape = (S, N) if sample_major else (N, S)
             T = np.empty(shape); Z = np.empty(shape); P = np.empty(shape)
@@ -192,3 +197,7 @@ def device_count():
 
 def set_waves_per_block(w):
     check(load().pgr_set_waves_per_block(int(w)))
+
+
+def set_park(lanes, trips):
+    check(load().pgr_set_park(int(lanes), int(trips)))

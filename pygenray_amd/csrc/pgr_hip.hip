@@ -44,6 +44,7 @@ struct EnvDev {
     int nr, nz, nb;
     int row_stride;  // nz, or 0 when the table is range independent (one stored row)
     int z_uniform, r_uniform, b_uniform;  // grid[j] == g0 + j*dg bitwise (host verified)
+    int beta_zero;  // all bottom angles are 0 -> the cubic is identically 0
     double z0, dz, inv_dz;
     double r0, dr, inv_dr;
     double b0, db, inv_db;
@@ -67,6 +68,9 @@ struct FanArgs {
     int32_t S;
     double x0, x1, rtol, atol;
     double inv_dsave;  // (S-1)/(x1-x0) guess for nearest-sample index
+    double save_step;  // linspace step when save_formula
+    int save_formula;  // r_save[j] == j*save_step + x0 bitwise (host verified)
+    int park_lanes, park_trips;  // service batching thresholds
     int64_t max_steps;
     uint32_t flags;
 };
@@ -301,24 +305,46 @@ struct Dense {
 #define P72 (-110615467.0 / 29380423)
 #define P73 (69997945.0 / 29380423)
 
-// np.argmin(np.abs(range_save - t)) (first minimum), REF/launch_rays.py:766-767
-__device__ __forceinline__ int nearest_sample(const double* __restrict__ r, int S, double x0,
-                                              double inv_ds, double t)
-{
-    double g = (t - x0) * inv_ds;
-    g = fmin(fmax(g, 0.0), (double)(S - 1));
-    int j = (int)rint(g);
-    int best = max(j - 1, 0);
-    double bd = fabs(r[best] - t);
-    for (int k = best + 1; k <= min(j + 1, S - 1); k++) {
-        double d = fabs(r[k] - t);
-        if (d < bd) { bd = d; best = k; }
+// the save grid np.linspace(x0, x1, S): either recomputed per index exactly as NumPy does
+// (arange(S) * step + start, last point forced to x1 -- verified bitwise on the host) or loaded
+struct SaveGrid {
+    const double* r;
+    double x0, x1, step, inv_step;
+    int S, formula;
+    __device__ __forceinline__ double at(int j) const
+    {
+        if (formula) return (j >= S - 1) ? x1 : ((double)j * step + x0);
+        return r[j];
     }
-    return best;
-}
+    // np.argmin(np.abs(range_save - t)) (first minimum), REF/launch_rays.py:766-767
+    __device__ __forceinline__ int nearest(double t) const
+    {
+        double g = (t - x0) * inv_step;
+        g = fmin(fmax(g, 0.0), (double)(S - 1));
+        int j = (int)rint(g);
+        int best = max(j - 1, 0);
+        double bd = fabs(at(best) - t);
+        for (int k = best + 1; k <= min(j + 1, S - 1); k++) {
+            double d = fabs(at(k) - t);
+            if (d < bd) { bd = d; best = k; }
+        }
+        return best;
+    }
+};
 
 // ------------------------------------------------------------------------------------
 // the fan kernel
+//
+// Lock-step structure.  Every lane owns one ray.  One trip of the main loop is one RK45
+// step ATTEMPT for every lane that is "stepping" (accept/reject is a per-lane select, so the
+// 6 right-hand-side evaluations run convergently).  Everything that happens only at a bounce
+// -- locating the event on the dense output, re-sampling up to it, the reflection law and the
+// restart of the integrator (2 more RHS evaluations, pow, asin/sin) -- costs about two step
+// attempts and would run with one or two live lanes per trip if it were done on the spot.
+// Instead a lane that accepted a step with an active event PARKS: it keeps the step's dense
+// output in registers and stops stepping until the wave runs a SERVICE phase for all parked
+// lanes together (when `park_lanes` lanes wait, or the oldest has waited `park_trips` trips, or
+// nobody else can step).  Per-ray arithmetic is unchanged by when the service runs.
 // ------------------------------------------------------------------------------------
 template <bool LDS_TAB>
 __global__ void __launch_bounds__(512)
@@ -331,12 +357,18 @@ pgr_fan_kernel(EnvDev env, FanArgs a)
         __syncthreads();
     }
     const Ctx<LDS_TAB> C(env, lds_tab);
-    const int64_t ray = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // waves are dealt to workgroups round-robin (wave w of block b = global wave w*grid + b):
+    // neighbouring launch angles cost alike, so a strided deal balances the CUs
+    const int64_t gwave = (int64_t)(threadIdx.x >> 6) * gridDim.x + blockIdx.x;
+    const int64_t ray = gwave * 64 + (threadIdx.x & 63);
     const bool valid = ray < a.N;
     const double SAFETY = 0.9, MIN_FACTOR = 0.2, MAX_FACTOR = 10;
     const double rtol = a.rtol, atol = a.atol, t_bound = a.x1;
     const int S = a.S;
     const bool save = (a.T != nullptr);
+    SaveGrid G;
+    G.r = a.r_save; G.x0 = a.x0; G.x1 = a.x1; G.step = a.save_step; G.inv_step = a.inv_dsave;
+    G.S = S; G.formula = a.save_formula;
 
     double t = a.x0, y0 = 0, y1 = 0, y2 = 0;
     if (valid) {
@@ -347,51 +379,224 @@ pgr_fan_kernel(EnvDev env, FanArgs a)
     double f0 = 0, f1 = 0, f2 = 0, h_abs = 0;
     unsigned g = 0;
     int status = valid ? RUNNING : PGR_RAY_OK;
-    bool need_init = true, rejected = false;
+    bool need_init = true, rejected = false, parked = false;
     int nb = 0, ns = 0, n_steps = 0, n_rej = 0;
     int jnext = 0;
     double rnext = 0;
+    // dense output of the step a parked lane is holding (t_old = t, y_old = y are still live)
+    Dense D;
+    D.t_old = 0; D.h = 1; D.y0 = D.y1 = D.y2 = 0;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) D.q[i][j] = 0;
+    double pk_tnew = 0;
+    unsigned pk_active = 0;
+    int waited = 0;
     double* Tp = save ? a.T + ray * a.stride_ray : nullptr;
     double* Zp = save ? a.Z + ray * a.stride_ray : nullptr;
     double* Pp = save ? a.P + ray * a.stride_ray : nullptr;
 
     while (__any(status == RUNNING)) {
-        if (status == RUNNING) {
-            if (need_init) {
-                // ---- fresh solve_ivp: RK45.__init__ (SCIPY/rk.py:84-104) ----
-                double c;
-                C.rhs(t, y1, y2, f0, f1, f2, c);
-                // select_initial_step, SCIPY/common.py:68-134 (order 4, direction +1, max_step inf)
-                double interval = fabs(t_bound - t);
-                double s0 = atol + fabs(y0) * rtol, s1 = atol + fabs(y1) * rtol,
-                       s2 = atol + fabs(y2) * rtol;
-                double d0 = rms3(y0 / s0, y1 / s1, y2 / s2);
-                double d1 = rms3(f0 / s0, f1 / s1, f2 / s2);
-                double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
-                if (!(h0 < interval)) h0 = interval;
-                double e0, e1, e2, cdummy;
-                C.rhs(t + h0 * 1.0, y1 + h0 * 1.0 * f1, y2 + h0 * 1.0 * f2, e0, e1, e2, cdummy);
-                double d2 = rms3((e0 - f0) / s0, (e1 - f1) / s1, (e2 - f2) / s2) / h0;
-                double h1;
-                if (d1 <= 1e-15 && d2 <= 1e-15) {
-                    h1 = h0 * 1e-3;
-                    if (!(h1 > 1e-6)) h1 = 1e-6;
-                } else {
-                    h1 = pow(0.01 / ((d2 > d1) ? d2 : d1), 1.0 / 5.0);
+        const bool run = (status == RUNNING);
+        const bool pend = run && (parked || need_init);
+        const unsigned long long pm = __ballot(pend);
+        if (pm) {
+            waited++;
+            const bool nobody_steps = !__any(run && !pend);
+            if (__popcll(pm) >= a.park_lanes || waited > a.park_trips || nobody_steps) {
+                waited = 0;
+                // =========================== SERVICE phase ===========================
+                if (pend && parked) {
+                    parked = false;
+                    const unsigned active = pk_active;
+                    const double t_new = pk_tnew, h = D.h;
+                    int ev = -1;
+                    double best = 0;
+                    if ((a.flags & PGR_EXACT_BISECTION) == 0 && (active == 1u || active == 2u)) {
+                        // ---- fast event location (default) ----
+                        // SciPy's brentq on the +-1 event degenerates to ~42 bisection steps, each a
+                        // dense-output + table evaluation.  The flip of a surface/bottom event is the
+                        // zero of the continuous function F(x) = z(x) [- bathy(x)] on the step's
+                        // quartic, so: safeguarded Newton on F (a handful of polynomial evaluations),
+                        // then two evaluations of the TRUE step-function event at x* -+ delta, delta =
+                        // brentq's own final half-width 2 EPS (1 + |x|).  If they bracket the flip the
+                        // answer x* + delta is within brentq's tolerance of SciPy's root; otherwise the
+                        // exact bisection below runs.
+                        const bool bottom = (active == 2u);
+                        const double q0 = D.q[1][0], q1 = D.q[1][1], q2 = D.q[1][2], q3 = D.q[1][3];
+                        double bs = 0, be = 0;
+                        if (bottom) { bs = C.bathy(t); be = C.bathy(t_new); }
+                        double zb = y1 + h * (q0 + q1 + q2 + q3);
+                        double Fa = bottom ? (y1 - bs) : y1;  // F at s = 0: not yet crossed
+                        double Fb = bottom ? (zb - be) : zb;  // F at s = 1: crossed
+                        // surface: F falls through 0 (z < 0 fires); bottom: F rises (z > bathy fires)
+                        bool pre = bottom ? (Fa <= 0 && Fb > 0) : (Fa >= 0 && Fb < 0);
+                        if (pre) {
+                            const double bslope = bottom ? (be - bs) : 0.0;  // per unit s
+                            double lo = 0.0, hi = 1.0;
+                            double sN = Fa / (Fa - Fb);  // secant start
+                            for (int it = 0; it < 12; it++) {
+                                double zs = y1 + h * (sN * (q0 + sN * (q1 + sN * (q2 + sN * q3))));
+                                double dz = h * (q0 + sN * (2 * q1 + sN * (3 * q2 + sN * 4 * q3)));
+                                double F = zs, dF = dz;
+                                if (bottom) { F = zs - C.bathy(t + sN * h); dF = dz - bslope; }
+                                bool crossed = bottom ? (F > 0) : (F < 0);
+                                if (crossed) hi = sN; else lo = sN;
+                                double sn = sN - F / dF;
+                                if (!(sn > lo && sn < hi)) sn = 0.5 * (lo + hi);
+                                double ds = fabs(sn - sN);
+                                sN = sn;
+                                if (ds * h < 1e-12 * (1.0 + fabs(t))) break;
+                            }
+                            double xs = t + sN * h;
+                            double delta = (4 * DBL_EPSILON + 4 * DBL_EPSILON * fabs(xs)) / 2;
+                            double xa = fmax(xs - delta, t), xb = fmin(xs + delta, t_new);
+                            double ez0, ez1, ez2, ec, ecp;
+                            D.eval(xa, ez0, ez1, ez2);
+                            C.lookup(xa, ez1, ec, ecp);
+                            bool ga = (C.events(xa, ez1, ez2, ec) & active) != 0;
+                            D.eval(xb, ez0, ez1, ez2);
+                            C.lookup(xb, ez1, ec, ecp);
+                            bool gb = (C.events(xb, ez1, ez2, ec) & active) != 0;
+                            if (!ga && gb) { best = xb; ev = bottom ? 1 : 0; }
+                        }
+                    }
+                    if (ev < 0) {
+                        // handle_events + solve_event_equation, SCIPY/ivp.py:51-131: brentq(xtol =
+                        // rtol = 4 EPS) on a +-1 step function == bisection (Q6).  All events are
+                        // terminal: the earliest root wins, ties go to the lowest event index.
+                        const double xtol = 4 * DBL_EPSILON, brtol = 4 * DBL_EPSILON;
+                        for (int k = 0; k < 4; k++) {
+                            if (!(active & (1u << k))) continue;
+                            double xpre = t, xcur = t_new, xblk = 0;
+                            double ez0, ez1, ez2, ec, ecp;
+                            D.eval(xpre, ez0, ez1, ez2);
+                            C.lookup(xpre, ez1, ec, ecp);
+                            bool fpre = (C.events(xpre, ez1, ez2, ec) >> k) & 1u;
+                            D.eval(xcur, ez0, ez1, ez2);
+                            C.lookup(xcur, ez1, ec, ecp);
+                            bool fcur = (C.events(xcur, ez1, ez2, ec) >> k) & 1u;
+                            if (fpre == fcur) { status = PGR_RAY_EVENT_ERROR; break; }
+                            for (int it = 0; it < 100; it++) {
+                                if (fpre != fcur) xblk = xpre;
+                                double delta = (xtol + brtol * fabs(xcur)) / 2;
+                                double sbis = (xblk - xcur) / 2;
+                                if (fabs(sbis) < delta) break;
+                                xpre = xcur;
+                                fpre = fcur;
+                                if (fabs(sbis) > delta) xcur += sbis;
+                                else xcur += (sbis > 0 ? delta : -delta);
+                                D.eval(xcur, ez0, ez1, ez2);
+                                C.lookup(xcur, ez1, ec, ecp);
+                                fcur = (C.events(xcur, ez1, ez2, ec) >> k) & 1u;
+                            }
+                            if (ev < 0 || xcur < best) { best = xcur; ev = k; }
+                        }
+                    }
+                    if (status == RUNNING) {
+                        const double t_end = best;
+                        // samples of this (truncated) step, REF/launch_rays.py:763-772 (Q5)
+                        if (save) {
+                            while (jnext < S - 1 && rnext <= t_end) {
+                                double o0, o1, o2;
+                                D.eval(rnext, o0, o1, o2);
+                                Tp[(int64_t)jnext * a.stride_smp] = o0;
+                                Zp[(int64_t)jnext * a.stride_smp] = o1;
+                                Pp[(int64_t)jnext * a.stride_smp] = o2;
+                                jnext++;
+                                rnext = G.at(jnext);
+                            }
+                        }
+                        // terminal event: t = root, y = sol(root) (SCIPY/ivp.py:689-692), then the
+                        // bounce logic of REF/launch_rays.py:432-480
+                        double r0, r1, r2;
+                        D.eval(t_end, r0, r1, r2);
+                        t = t_end; y0 = r0; y1 = r1; y2 = r2;
+                        if (ev == 2) status = PGR_RAY_VERTICAL;
+                        else if (ev == 3) status = PGR_RAY_BBOX;
+                        else {
+                            double c, cp;
+                            C.lookup(t, y1, c, cp);
+                            double theta = asin(y2 * c) * (180.0 / M_PI);  // ray_angle
+                            double theta_b;
+                            if (ev == 0) {
+                                theta_b = -theta;
+                                ns++;
+                            } else {
+                                // beta = interp1d(depth_ranges, bottom_angles, 'cubic')(x)
+                                const double* xr = env.depth_ranges;
+                                if (!(t >= xr[0] && t <= xr[env.nb - 1])) {
+                                    status = PGR_RAY_BETA_RANGE;
+                                    theta_b = 0;
+                                } else {
+                                    double beta = 0.0;
+                                    if (!env.beta_zero) {
+                                        int i;
+                                        double xi;
+                                        if (env.b_uniform) {
+                                            i = cell_uniform(t, env.b0, env.db, env.inv_db, env.nb);
+                                            xi = env.b0 + (double)i * env.db;
+                                        } else {
+                                            i = cell_search(t, xr, env.nb);
+                                            xi = xr[i];
+                                        }
+                                        double u = t - xi;
+                                        const double* q = env.pp + 4 * i;
+                                        beta = q[0] + u * (q[1] + u * (q[2] + u * q[3]));
+                                    }
+                                    theta_b = 2 * beta - theta;
+                                    nb++;
+                                }
+                            }
+                            if (status == RUNNING) {
+                                if ((a.flags & PGR_TERMINATE_BACKWARDS) && (fabs(theta_b) > 90))
+                                    status = PGR_RAY_BACKWARD;
+                                else {
+                                    y2 = sin(theta_b * (M_PI / 180.0)) / c;
+                                    need_init = true;
+                                    if (!(t < t_bound)) status = PGR_RAY_OK;
+                                    else if (n_steps > a.max_steps) status = PGR_RAY_MAX_STEPS;
+                                }
+                            }
+                        }
+                    }
                 }
-                h_abs = 100 * h0;
-                if (h1 < h_abs) h_abs = h1;
-                if (interval < h_abs) h_abs = interval;
-                // g = [event(t0, y0) ...], SCIPY/ivp.py:649
-                g = C.events(t, y1, y2, c);
-                rejected = false;
-                need_init = false;
-                if (save) {
-                    jnext = nearest_sample(a.r_save, S, a.x0, a.inv_dsave, t);
-                    rnext = a.r_save[jnext];
+                if (status == RUNNING && need_init) {
+                    // ---- fresh solve_ivp: RK45.__init__ (SCIPY/rk.py:84-104) ----
+                    double c;
+                    C.rhs(t, y1, y2, f0, f1, f2, c);
+                    // select_initial_step, SCIPY/common.py:68-134 (order 4, direction +1, max_step inf)
+                    double interval = fabs(t_bound - t);
+                    double s0 = atol + fabs(y0) * rtol, s1 = atol + fabs(y1) * rtol,
+                           s2 = atol + fabs(y2) * rtol;
+                    double d0 = rms3(y0 / s0, y1 / s1, y2 / s2);
+                    double d1 = rms3(f0 / s0, f1 / s1, f2 / s2);
+                    double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+                    if (!(h0 < interval)) h0 = interval;
+                    double e0, e1, e2, cdummy;
+                    C.rhs(t + h0 * 1.0, y1 + h0 * 1.0 * f1, y2 + h0 * 1.0 * f2, e0, e1, e2, cdummy);
+                    double d2 = rms3((e0 - f0) / s0, (e1 - f1) / s1, (e2 - f2) / s2) / h0;
+                    double h1;
+                    if (d1 <= 1e-15 && d2 <= 1e-15) {
+                        h1 = h0 * 1e-3;
+                        if (!(h1 > 1e-6)) h1 = 1e-6;
+                    } else {
+                        h1 = pow(0.01 / ((d2 > d1) ? d2 : d1), 1.0 / 5.0);
+                    }
+                    h_abs = 100 * h0;
+                    if (h1 < h_abs) h_abs = h1;
+                    if (interval < h_abs) h_abs = interval;
+                    // g = [event(t0, y0) ...], SCIPY/ivp.py:649
+                    g = C.events(t, y1, y2, c);
+                    rejected = false;
+                    need_init = false;
+                    if (save) {
+                        jnext = G.nearest(t);
+                        rnext = G.at(jnext);
+                    }
                 }
             }
+        }
 
+        if (status == RUNNING && !parked && !need_init) {
             // ---- one attempt of RK45._step_impl, SCIPY/rk.py:111-176 ----
             double min_step = 10 * fabs(nextafter(t, INFINITY) - t);
             if (!rejected && h_abs < min_step) h_abs = min_step;  // clamp only on entry
@@ -464,9 +669,6 @@ pgr_fan_kernel(EnvDev env, FanArgs a)
                 unsigned active = (up & 3u) | ((up | down) & 12u);
                 g = g_new;
                 bool want_samples = save && (jnext < S - 1) && (rnext <= t_new);
-                double t_end = t_new;
-                int ev = -1;
-                Dense D;
                 if (active || want_samples) {
                     D.t_old = t; D.h = h; D.y0 = y0; D.y1 = y1; D.y2 = y2;
                     D.q[0][0] = PQ(f0, k30, k40, k50, k60, k70, 0);
@@ -483,101 +685,28 @@ pgr_fan_kernel(EnvDev env, FanArgs a)
                     D.q[2][3] = PQ(f2, k32, k42, k52, k62, k72, 3);
                 }
                 if (active) {
-                    // handle_events + solve_event_equation, SCIPY/ivp.py:51-131: brentq(xtol = rtol =
-                    // 4 EPS) on a +-1 step function == bisection (Q6).  All events are terminal:
-                    // the earliest root wins, ties go to the lowest event index.
-                    const double xtol = 4 * DBL_EPSILON, brtol = 4 * DBL_EPSILON;
-                    double best = 0;
-                    for (int k = 0; k < 4; k++) {
-                        if (!(active & (1u << k))) continue;
-                        double xpre = t, xcur = t_new, xblk = 0;
-                        double ez0, ez1, ez2, ec, ecp;
-                        D.eval(xpre, ez0, ez1, ez2);
-                        C.lookup(xpre, ez1, ec, ecp);
-                        bool fpre = (C.events(xpre, ez1, ez2, ec) >> k) & 1u;
-                        D.eval(xcur, ez0, ez1, ez2);
-                        C.lookup(xcur, ez1, ec, ecp);
-                        bool fcur = (C.events(xcur, ez1, ez2, ec) >> k) & 1u;
-                        if (fpre == fcur) { status = PGR_RAY_EVENT_ERROR; break; }
-                        for (int it = 0; it < 100; it++) {
-                            if (fpre != fcur) xblk = xpre;
-                            double delta = (xtol + brtol * fabs(xcur)) / 2;
-                            double sbis = (xblk - xcur) / 2;
-                            if (fabs(sbis) < delta) break;
-                            xpre = xcur;
-                            fpre = fcur;
-                            if (fabs(sbis) > delta) xcur += sbis;
-                            else xcur += (sbis > 0 ? delta : -delta);
-                            D.eval(xcur, ez0, ez1, ez2);
-                            C.lookup(xcur, ez1, ec, ecp);
-                            fcur = (C.events(xcur, ez1, ez2, ec) >> k) & 1u;
-                        }
-                        if (ev < 0 || xcur < best) { best = xcur; ev = k; }
-                    }
-                    if (status == RUNNING) t_end = best;
-                }
-                // ---- _interpolate_ray, streamed (REF/launch_rays.py:763-772, Q5): samples of the
-                // segment slice [idx1, idx2) that this step's quartic owns ----
-                if (save && status == RUNNING) {
-                    while (jnext < S - 1 && rnext <= t_end) {
-                        double o0, o1, o2;
-                        D.eval(rnext, o0, o1, o2);
-                        Tp[(int64_t)jnext * a.stride_smp] = o0;
-                        Zp[(int64_t)jnext * a.stride_smp] = o1;
-                        Pp[(int64_t)jnext * a.stride_smp] = o2;
-                        jnext++;
-                        rnext = a.r_save[jnext];
-                    }
-                }
-                if (status == RUNNING) {
-                    if (ev < 0) {
-                        t = t_new; y0 = n0; y1 = n1; y2 = n2;
-                        f0 = k70; f1 = k71; f2 = k72;
-                        if ((t - t_bound) >= 0) status = PGR_RAY_OK;  // SCIPY/base.py:197
-                        else if (n_steps > a.max_steps) status = PGR_RAY_MAX_STEPS;
-                    } else {
-                        // terminal event: t = root, y = sol(root) (SCIPY/ivp.py:689-692), then the
-                        // bounce logic of REF/launch_rays.py:432-480
-                        double r0, r1, r2;
-                        D.eval(t_end, r0, r1, r2);
-                        t = t_end; y0 = r0; y1 = r1; y2 = r2;
-                        if (ev == 2) status = PGR_RAY_VERTICAL;
-                        else if (ev == 3) status = PGR_RAY_BBOX;
-                        else {
-                            double c, cp;
-                            C.lookup(t, y1, c, cp);
-                            double theta = asin(y2 * c) * (180.0 / M_PI);  // ray_angle
-                            double theta_b;
-                            if (ev == 0) {
-                                theta_b = -theta;
-                                ns++;
-                            } else {
-                                // beta = interp1d(depth_ranges, bottom_angles, 'cubic')(x)
-                                const double* xr = env.depth_ranges;
-                                if (!(t >= xr[0] && t <= xr[env.nb - 1])) {
-                                    status = PGR_RAY_BETA_RANGE;
-                                    theta_b = 0;
-                                } else {
-                                    int i = cell_search(t, xr, env.nb);
-                                    double u = t - xr[i];
-                                    const double* q = env.pp + 4 * i;
-                                    double beta = q[0] + u * (q[1] + u * (q[2] + u * q[3]));
-                                    theta_b = 2 * beta - theta;
-                                    nb++;
-                                }
-                            }
-                            if (status == RUNNING) {
-                                if ((a.flags & PGR_TERMINATE_BACKWARDS) && (fabs(theta_b) > 90))
-                                    status = PGR_RAY_BACKWARD;
-                                else {
-                                    y2 = sin(theta_b * (M_PI / 180.0)) / c;
-                                    need_init = true;
-                                    if (!(t < t_bound)) status = PGR_RAY_OK;
-                                    else if (n_steps > a.max_steps) status = PGR_RAY_MAX_STEPS;
-                                }
-                            }
+                    // park: the step is located, truncated and bounced in the next service phase
+                    parked = true;
+                    pk_active = active;
+                    pk_tnew = t_new;
+                } else {
+                    // ---- _interpolate_ray, streamed (REF/launch_rays.py:763-772, Q5): samples of the
+                    // segment slice [idx1, idx2) that this step's quartic owns ----
+                    if (want_samples) {
+                        while (jnext < S - 1 && rnext <= t_new) {
+                            double o0, o1, o2;
+                            D.eval(rnext, o0, o1, o2);
+                            Tp[(int64_t)jnext * a.stride_smp] = o0;
+                            Zp[(int64_t)jnext * a.stride_smp] = o1;
+                            Pp[(int64_t)jnext * a.stride_smp] = o2;
+                            jnext++;
+                            rnext = G.at(jnext);
                         }
                     }
+                    t = t_new; y0 = n0; y1 = n1; y2 = n2;
+                    f0 = k70; f1 = k71; f2 = k72;
+                    if ((t - t_bound) >= 0) status = PGR_RAY_OK;  // SCIPY/base.py:197
+                    else if (n_steps > a.max_steps) status = PGR_RAY_MAX_STEPS;
                 }
             }
         }
@@ -634,6 +763,7 @@ __global__ void pgr_eval_kernel(EnvDev env, const double* x, const double* y, in
 // ====================================================================================
 static thread_local std::string g_err;
 static int g_waves_per_block = 0;
+static int g_park_lanes = 64, g_park_trips = 64;
 
 static int fail(const std::string& m)
 {
@@ -664,6 +794,14 @@ extern "C" int pgr_device_count(void)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) { fail("hipGetDeviceCount failed"); return -1; }
     return n;
+}
+
+extern "C" int pgr_set_park(int lanes, int trips)
+{
+    if (lanes < 1 || lanes > 64 || trips < 0 || trips > 100000) return fail("pgr_set_park: lanes in [1,64], trips >= 0");
+    g_park_lanes = lanes;
+    g_park_trips = trips;
+    return 0;
 }
 
 extern "C" int pgr_set_waves_per_block(int waves)
@@ -817,6 +955,8 @@ extern "C" int pgr_env_create(pgr_env** out, int device, const double* cin, cons
     d.r_uniform = exactly_uniform(rin, nr, d.r0, d.dr);
     d.inv_dr = d.r_uniform ? 1.0 / d.dr : 0.0;
     d.b_uniform = exactly_uniform(depth_ranges, nb, d.b0, d.db);
+    d.beta_zero = 1;
+    for (double v : pp) if (v != 0.0) d.beta_zero = 0;
     d.inv_db = d.b_uniform ? 1.0 / d.db : 0.0;
     const double tol = 1e-6;
     d.zhi_tol = zin[nz - 1] + tol;
@@ -869,6 +1009,11 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
     else { a.stride_ray = S; a.stride_smp = 1; }
     a.x0 = source_range; a.x1 = receiver_range; a.rtol = rtol; a.atol = atol;
     a.inv_dsave = (S > 1 && receiver_range != source_range) ? (double)(S - 1) / (receiver_range - source_range) : 0.0;
+    // np.linspace: step = (stop - start) / (num - 1); y = arange(num) * step + start; y[-1] = stop
+    a.save_step = (S > 1) ? (receiver_range - source_range) / (double)(S - 1) : 0.0;
+    a.save_formula = (flags & PGR_SAVE_LINSPACE) ? 1 : 0;
+    a.park_lanes = g_park_lanes;
+    a.park_trips = g_park_trips;
     a.max_steps = max_steps; a.flags = flags;
 
     int64_t waves = (N + 63) / 64;
@@ -928,6 +1073,19 @@ extern "C" int pgr_shoot_fan(pgr_env* env, const double* y0, int64_t N, double s
         return fail("pgr_shoot_fan: device allocation failed");
     HIPCHK(hipMemcpy(dy0.p, y0, N * 3 * sizeof(double), hipMemcpyHostToDevice));
     if (save) HIPCHK(hipMemcpy(dr.p, r_save, (size_t)S * sizeof(double), hipMemcpyHostToDevice));
+    if (save) {
+        // is r_save exactly np.linspace(source_range, receiver_range, S)?  then the kernel
+        // recomputes it per index instead of loading it
+        double step = (S > 1) ? (receiver_range - source_range) / (double)(S - 1) : 0.0;
+        bool lin = true;
+        for (int32_t j = 0; j < S && lin; j++) {
+            volatile double m = (double)j * step;
+            volatile double v = m + source_range;
+            double want = (j == S - 1 && S > 1) ? receiver_range : (double)v;
+            lin = (r_save[j] == want);
+        }
+        if (lin) flags |= PGR_SAVE_LINSPACE; else flags &= ~PGR_SAVE_LINSPACE;
+    }
     int rc = pgr_shoot_fan_device(env, (const double*)dy0.p, N, source_range, receiver_range,
                                   (const double*)dr.p, S, rtol, atol, flags, max_steps,
                                   save ? (double*)dT.p : nullptr, save ? (double*)dZ.p : nullptr,
