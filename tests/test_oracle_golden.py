@@ -207,6 +207,7 @@ def test_linear_gradient_and_flatearth_nonuniform_grid():
         n["status"] = np.where(n["status"] == 0, 0, -1)
         for nm in "Tzp":
             n[nm] = n[nm][:, ::4]
+        n["xi"] = n["xi"][:, ::4][:, :-1]
     # the golden's last column is the sub-sampled grid's last point (index 396), not the end state
     good_cols = slice(0, -1)
     for d in (test, ref, *noise):
