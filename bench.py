@@ -86,8 +86,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rays", type=int, default=RAYS_PER_GPU, help="rays per GPU")
-    ap.add_argument("--layout", choices=["ray", "sample"], default="ray",
-                    help="trajectory layout in HBM: [N][S] (pygenray's RayFan) or [S][N]")
+    ap.add_argument("--layout", choices=["ray", "sample"], default="sample",
+                    help="trajectory layout in HBM: [S][N] (default: coalesced stores; the drop-in API\n"
+                         "hands RayFan a transposed (N,S) view of it) or [N][S] (4.4x HBM write amplification)")
     ap.add_argument("--no-save", action="store_true", help="end state only (B_alg = 80 B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--waves-per-block", type=int, default=0)
@@ -167,14 +168,17 @@ def main():
         mean_steps = local_steps / max(fan.N - int((fan.status != 0).sum().item()), 1)
         b_alg = 80.0 + (24.0 * S_SAVE / mean_steps if save else 0.0)
         achieved = local_steps * b_alg / (kern_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+        # (profiles/r01_traffic.json: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE)
+        traffic = traffic_gb = None
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 key = f"{args.layout}{'' if save else '-nosave'}"
                 if key in tj and tj[key].get("rays") == fan.N:
-                    traffic = tj[key]["hbm_gb_per_launch"]
+                    traffic_gb = tj[key]["hbm_gb_per_launch"]
+                    traffic = traffic_gb / (kern_ms * 1e-3)
             except Exception:
                 traffic = None
         out = {
@@ -190,6 +194,8 @@ def main():
                        "sharding": "strided launch angles, all-gather of end records" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_gb_per_launch": traffic_gb,
+                         "algorithmic_gb_per_launch": local_steps * b_alg / 1e9,
                          "kernel": "pgr_fan_kernel<LDS table>", "kernel_ms": kern_ms,
                          "bytes_per_ray_step": b_alg,
                          "note": "algorithmic bytes per SURVEY 8(d); the stepper keeps state in "

@@ -61,8 +61,13 @@ def _shoot_ode_angles(source_depth, source_range, ode_angles_deg, receiver_range
     if not (source_range_i < receiver_range_i):
         # the reference's bounce loop never runs and _interpolate_ray indexes an empty list
         raise IndexError("list index out of range")
+    # trajectories come back sample-major ([S][N]: coalesced stores on the device, 4x less HBM
+    # write traffic) and are handed on as transposed (N, S) views -- same indexing as pygenray
     out = env.shoot_fan(y0, source_range_i, receiver_range_i, num_range_save, rtol=rtol,
-                        terminate_backwards=terminate_backwards, save=save, max_steps=max_steps)
+                        terminate_backwards=terminate_backwards, save=save, max_steps=max_steps,
+                        sample_major=True)
+    if save:
+        out["T"], out["z"], out["p"] = out["T"].T, out["z"].T, out["p"].T
     if backwards:
         out["r"] = -out["r"]
     return out
