@@ -114,6 +114,10 @@ int pgr_set_park(int lanes, int trips);
  *   linear_interp at x. */
 int pgr_eval_points(pgr_env* env, const double* x, const double* y, int64_t M, double* out10);
 
+/* Accuracy probe of the kernel's arithmetic building blocks (tests only): for HOST arrays a, b
+ * of length M, out[k] = { a/b, 1/b, 1/sqrt(b), sqrt(b), b^-0.2, 10*ulp(a) } as the kernel computes them. */
+int pgr_debug_math(const double* a, const double* b, int64_t M, double* out6);
+
 /* Message for the last error on the calling thread. */
 const char* pgr_last_error(void);
 

@@ -14,8 +14,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libpgr_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-               "-ffp-contract=off"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
+if os.environ.get("PGR_FMA"):      # experiments only: FMA contraction + 2-ulp rsqrt (breaks 1e-8 parity)
+    HIPCC_FLAGS += ["-DPGR_FMA", "-ffp-contract=fast"]
+elif os.environ.get("PGR_STRICT"):  # compiler's IEEE divide/sqrt and pow()
+    HIPCC_FLAGS += ["-DPGR_STRICT", "-ffp-contract=off"]
+else:                               # default: reference arithmetic, cheaper correctly-rounded div/sqrt
+    HIPCC_FLAGS += ["-ffp-contract=off"]
 
 PGR_TERMINATE_BACKWARDS = 1
 PGR_SAMPLE_MAJOR = 2
@@ -189,6 +194,16 @@ class EnvHandle:
         out = np.empty((len(x), 10))
         check(load().pgr_eval_points(self._h, _p(x), _p(y), len(x), _p(out)))
         return out
+
+
+def debug_math(a, b):
+    a = _c(a); b = _c(b)
+    out = np.empty((len(a), 6))
+    L = load()
+    L.pgr_debug_math.restype = ctypes.c_int
+    L.pgr_debug_math.argtypes = [_dp, _dp, _i64, _dp]
+    check(L.pgr_debug_math(_p(a), _p(b), len(a), _p(out)))
+    return out
 
 
 def device_count():

@@ -45,6 +45,7 @@ struct EnvDev {
     int row_stride;  // nz, or 0 when the table is range independent (one stored row)
     int z_uniform, r_uniform, b_uniform;  // grid[j] == g0 + j*dg bitwise (host verified)
     int beta_zero;  // all bottom angles are 0 -> the cubic is identically 0
+    int z_pow2;     // z_uniform, dz a power of two and every zin[j+1]-zin[j] == dz bitwise
     double z0, dz, inv_dz;
     double r0, dr, inv_dr;
     double b0, db, inv_db;
@@ -78,6 +79,136 @@ struct FanArgs {
 #define RUNNING (-1)
 
 // ------------------------------------------------------------------------------------
+// arithmetic building blocks
+//
+// The adaptive controller makes the solution extremely sensitive to rounding: the embedded
+// error estimate is a near-cancelling sum (~1e-8 relative rounding noise), err^-0.2 feeds it
+// into every following step size, and a 1e-9 relative change of the step sequence moves a
+// 1000 km ray by millimetres (1e-6 relative) -- measured by building this file with FMA
+// contraction on (-DPGR_FMA).  To stay within 1e-8 of the CPU reference the default build
+// therefore reproduces the reference's IEEE arithmetic operation by operation
+// (-ffp-contract=off) and only replaces the *expansions* of divide and sqrt by cheaper ones
+// that are still correctly rounded for the operand ranges that occur here:
+//   * a/b: two Newton steps on v_rcp_f64 + one Markstein correction (8 VALU ops instead of the
+//     ~14 of the generic expansion with v_div_scale / v_div_fmas / v_div_fixup).  Correctly
+//     rounded unless the exact quotient is within ~2^-104 of a rounding boundary (0 mismatches
+//     in 2e6 random operands, tests/test_hip_parity.py::test_arithmetic_building_blocks);
+//   * sqrt: v_rsq_f64 + Newton + one residual correction (0 mismatches in 2e6);
+//   * err^-0.2: Newton on y^-5 = err from an fp32 seed, <= 2 ulp (pow() is not correctly
+//     rounded in libm or ocml either); 10*ulp(t) by integer arithmetic (exact).
+// -DPGR_STRICT uses the compiler's IEEE divide/sqrt and pow(); -DPGR_FMA additionally allows
+// contraction and a 2-ulp rsqrt (fastest, NOT within 1e-8 of the reference: experiments only).
+// ------------------------------------------------------------------------------------
+#ifdef PGR_STRICT
+#define PGR_FAST 0
+#else
+#define PGR_FAST 1
+#endif
+
+__device__ __forceinline__ double frcp(double b)
+{
+#if PGR_FAST
+    double y = __builtin_amdgcn_rcp(b);
+    double e = fma(-b, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-b, y, 1.0);
+    y = fma(y, e, y);
+    return y;
+#else
+    return 1.0 / b;
+#endif
+}
+__device__ __forceinline__ double fdiv(double a, double b)
+{
+#if PGR_FAST
+    double y = frcp(b);
+    double q = a * y;
+    double r = fma(-q, b, a);
+    return fma(r, y, q);
+#else
+    return a / b;
+#endif
+}
+// q = a / b given y ~ 1/b (shared reciprocal)
+__device__ __forceinline__ double fdiv_y(double a, double b, double y)
+{
+    double q = a * y;
+    double r = fma(-q, b, a);
+    return fma(r, y, q);
+}
+// 1/sqrt(x), x > 0 and normal: raw Newton form (<= 2 ulp), building block of fsqrt
+__device__ __forceinline__ double frsqrt_raw(double x)
+{
+#if PGR_FAST
+    double y = __builtin_amdgcn_rsq(x);
+    // two Newton steps: y <- y + y*(1 - x y^2)/2
+    double e = fma(-x * y, y, 1.0);
+    y = fma(y * 0.5, e, y);
+    e = fma(-x * y, y, 1.0);
+    y = fma(y * 0.5, e, y);
+    return y;
+#else
+    return 1 / sqrt(x);
+#endif
+}
+__device__ __forceinline__ double fsqrt(double x)
+{
+#if PGR_FAST
+    if (!(x > 0)) return (x == 0) ? 0.0 : sqrt(x);
+    double y = frsqrt_raw(x);
+    double g = x * y;
+    double d = fma(-g, g, x);  // residual
+    return fma(d * 0.5, y, g);
+#else
+    return sqrt(x);
+#endif
+}
+// the reference's `1 / np.sqrt(arg)`: RN(1 / RN(sqrt x))
+__device__ __forceinline__ double frsqrt(double x)
+{
+#ifdef PGR_FMA
+    return frsqrt_raw(x);
+#else
+    return frcp(fsqrt(x));
+#endif
+}
+// err^(-1/5) for err in [1e-7, 1e4]
+__device__ __forceinline__ double pow_m02(double x)
+{
+#if PGR_FAST
+    float xf = (float)x;
+    double y = (double)__builtin_amdgcn_exp2f(-0.2f * __builtin_amdgcn_logf(xf));
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        double y2 = y * y, y4 = y2 * y2, y5 = y4 * y;
+        double e = fma(-x, y5, 1.0);
+        y = fma(y * 0.2, e, y);
+    }
+    return y;
+#else
+    return pow(x, -0.2);
+#endif
+}
+// 10 * |nextafter(t, +inf) - t|, SCIPY/rk.py:119
+__device__ __forceinline__ double min_step_of(double t)
+{
+#if PGR_FAST
+    long long b = __double_as_longlong(t);
+    double nx = (t == 0.0) ? 4.9406564584124654e-324 : __longlong_as_double(t > 0 ? b + 1 : b - 1);
+    return 10 * fabs(nx - t);
+#else
+    return 10 * fabs(nextafter(t, INFINITY) - t);
+#endif
+}
+// g0 + j*dg with NO contraction: must reproduce the table coordinate bit for bit
+__device__ __forceinline__ double grid_at(double g0, double dg, int j)
+{
+#pragma clang fp contract(off)
+    double m = (double)j * dg;
+    return g0 + m;
+}
+
+// ------------------------------------------------------------------------------------
 // grid cell lookup: np.searchsorted(grid, q) - 1 clamped to [0, n-2]
 // (REF/integration_processes.py:152-157).  side='left': grid[j] < q <= grid[j+1].
 // ------------------------------------------------------------------------------------
@@ -86,13 +217,8 @@ __device__ __forceinline__ int cell_uniform(double q, double g0, double dg, doub
     double t = (q - g0) * inv_dg;
     t = fmin(fmax(t, -1.0), (double)n);  // NaN -> -1
     int j = (int)floor(t);
-    double gj = g0 + (double)j * dg;
-    if (gj >= q) {
-        j -= 1;
-    } else {
-        double gj1 = g0 + (double)(j + 1) * dg;
-        if (gj1 < q) j += 1;
-    }
+    double gj = grid_at(g0, dg, j), gj1 = grid_at(g0, dg, j + 1);
+    j += (gj >= q) ? -1 : ((gj1 < q) ? 1 : 0);
     return min(max(j, 0), n - 2);
 }
 
@@ -120,8 +246,8 @@ struct Ctx {
         int j;
         if (e.z_uniform) {
             j = cell_uniform(z, e.z0, e.dz, e.inv_dz, e.nz);
-            zj = e.z0 + (double)j * e.dz;
-            zj1 = e.z0 + (double)(j + 1) * e.dz;
+            zj = grid_at(e.z0, e.dz, j);
+            zj1 = grid_at(e.z0, e.dz, j + 1);
         } else {
             j = cell_search(z, e.zin, e.nz);
             zj = e.zin[j];
@@ -134,8 +260,8 @@ struct Ctx {
         int i;
         if (e.r_uniform) {
             i = cell_uniform(x, e.r0, e.dr, e.inv_dr, e.nr);
-            ri = e.r0 + (double)i * e.dr;
-            ri1 = e.r0 + (double)(i + 1) * e.dr;
+            ri = grid_at(e.r0, e.dr, i);
+            ri1 = grid_at(e.r0, e.dr, i + 1);
         } else {
             i = cell_search(x, e.rin, e.nr);
             ri = e.rin[i];
@@ -150,8 +276,9 @@ struct Ctx {
         double ri, ri1, zj, zj1;
         int i = cell_r(x, ri, ri1);
         int j = cell_z(z, zj, zj1);
-        double wx = (x - ri) / (ri1 - ri);
-        double wy = (z - zj) / (zj1 - zj);
+        double wx = fdiv(x - ri, ri1 - ri);
+        // every cell is exactly dz wide and dz is a power of two: the division is an exact scaling
+        double wy = e.z_pow2 ? (z - zj) * e.inv_dz : fdiv(z - zj, zj1 - zj);
         double2 v00, v01, v10, v11;
         if (LDS_TAB) {
             v00 = lds[j];
@@ -177,14 +304,14 @@ struct Ctx {
         double xi, xi1;
         if (e.b_uniform) {
             i = cell_uniform(x, e.b0, e.db, e.inv_db, e.nb);
-            xi = e.b0 + (double)i * e.db;
-            xi1 = e.b0 + (double)(i + 1) * e.db;
+            xi = grid_at(e.b0, e.db, i);
+            xi1 = grid_at(e.b0, e.db, i + 1);
         } else {
             i = cell_search(x, e.depth_ranges, e.nb);
             xi = e.depth_ranges[i];
             xi1 = e.depth_ranges[i + 1];
         }
-        double w = (x - xi) / (xi1 - xi);
+        double w = fdiv(x - xi, xi1 - xi);
         return (1 - w) * e.depths[i] + w * e.depths[i + 1];
     }
 
@@ -196,10 +323,18 @@ struct Ctx {
         lookup(x, z, c, cp);
         double arg = 1.0 - (c * c) * (pz * pz);
         if (arg <= 0.0) arg = 1e-30;
+#if PGR_FAST
+        double fact = frsqrt(arg);
+        double rc = frcp(c);
+        d0 = fdiv_y(fact, c, rc);
+        d1 = c * pz * fact;
+        d2 = fdiv_y(-fact * cp, c * c, rc * rc);
+#else
         double fact = 1 / sqrt(arg);
         d0 = fact / c;
         d1 = c * pz * fact;
         d2 = -fact * cp / (c * c);
+#endif
     }
 
     // the four +-1 events (REF/integration_processes.py:238-303) as a bit mask, bit k = event
@@ -258,7 +393,11 @@ struct Ctx {
 __device__ __forceinline__ double rms3(double a, double b, double c)
 {
     // np.linalg.norm(x) / x.size ** 0.5, SCIPY/common.py:63-65
+#if PGR_FAST
+    return fdiv(fsqrt(a * a + b * b + c * c), 1.7320508075688772);
+#else
     return sqrt(a * a + b * b + c * c) / 1.7320508075688772;
+#endif
 }
 
 // quartic dense output of one accepted step: Q = K.T @ P (SCIPY/rk.py:178-180, 393-404)
@@ -269,7 +408,7 @@ struct Dense {
     __device__ __forceinline__ void eval(double t, double& o0, double& o1, double& o2) const
     {
         // SCIPY/rk.py:560-574: x = (t - t_old)/h ; p = cumprod ; y = h * (Q @ p) + y_old
-        double x = (t - t_old) / h;
+        double x = fdiv(t - t_old, h);
         double p1 = x, p2 = p1 * x, p3 = p2 * x, p4 = p3 * x;
         o0 = h * (q[0][0] * p1 + q[0][1] * p2 + q[0][2] * p3 + q[0][3] * p4) + y0;
         o1 = h * (q[1][0] * p1 + q[1][1] * p2 + q[1][2] * p3 + q[1][3] * p4) + y1;
@@ -313,7 +452,7 @@ struct SaveGrid {
     int S, formula;
     __device__ __forceinline__ double at(int j) const
     {
-        if (formula) return (j >= S - 1) ? x1 : ((double)j * step + x0);
+        if (formula) return (j >= S - 1) ? x1 : grid_at(x0, step, j);
         return r[j];
     }
     // np.argmin(np.abs(range_save - t)) (first minimum), REF/launch_rays.py:766-767
@@ -533,7 +672,7 @@ pgr_fan_kernel(EnvDev env, FanArgs a)
                                         double xi;
                                         if (env.b_uniform) {
                                             i = cell_uniform(t, env.b0, env.db, env.inv_db, env.nb);
-                                            xi = env.b0 + (double)i * env.db;
+                                            xi = grid_at(env.b0, env.db, i);
                                         } else {
                                             i = cell_search(t, xr, env.nb);
                                             xi = xr[i];
@@ -598,7 +737,7 @@ pgr_fan_kernel(EnvDev env, FanArgs a)
 
         if (status == RUNNING && !parked && !need_init) {
             // ---- one attempt of RK45._step_impl, SCIPY/rk.py:111-176 ----
-            double min_step = 10 * fabs(nextafter(t, INFINITY) - t);
+            double min_step = min_step_of(t);
             if (!rejected && h_abs < min_step) h_abs = min_step;  // clamp only on entry
             bool too_small = h_abs < min_step;
             double h = h_abs;
@@ -630,9 +769,9 @@ pgr_fan_kernel(EnvDev env, FanArgs a)
             double sc0 = atol + fmax(fabs(y0), fabs(n0)) * rtol;
             double sc1 = atol + fmax(fabs(y1), fabs(n1)) * rtol;
             double sc2 = atol + fmax(fabs(y2), fabs(n2)) * rtol;
-            double er0 = ((f0 * E1 + k30 * E3 + k40 * E4 + k50 * E5 + k60 * E6 + k70 * E7) * h) / sc0;
-            double er1 = ((f1 * E1 + k31 * E3 + k41 * E4 + k51 * E5 + k61 * E6 + k71 * E7) * h) / sc1;
-            double er2 = ((f2 * E1 + k32 * E3 + k42 * E4 + k52 * E5 + k62 * E6 + k72 * E7) * h) / sc2;
+            double er0 = fdiv((f0 * E1 + k30 * E3 + k40 * E4 + k50 * E5 + k60 * E6 + k70 * E7) * h, sc0);
+            double er1 = fdiv((f1 * E1 + k31 * E3 + k41 * E4 + k51 * E5 + k61 * E6 + k71 * E7) * h, sc1);
+            double er2 = fdiv((f2 * E1 + k32 * E3 + k42 * E4 + k52 * E5 + k62 * E6 + k72 * E7) * h, sc2);
             double error_norm = rms3(er0, er1, er2);
 
             bool accepted = false;
@@ -640,10 +779,11 @@ pgr_fan_kernel(EnvDev env, FanArgs a)
                 status = PGR_RAY_STEP_TOO_SMALL;
             } else if (error_norm < 1) {
                 double factor;
-                if (error_norm == 0) {
+                // min(MAX_FACTOR, SAFETY * err^-0.2): the clamp is active below (0.09)^5 = 5.9e-6
+                if (error_norm < 5.0e-6) {
                     factor = MAX_FACTOR;
                 } else {
-                    factor = SAFETY * pow(error_norm, -0.2);
+                    factor = SAFETY * pow_m02(error_norm);
                     if (!(factor < MAX_FACTOR)) factor = MAX_FACTOR;
                 }
                 if (rejected && !(factor < 1)) factor = 1;
@@ -651,8 +791,12 @@ pgr_fan_kernel(EnvDev env, FanArgs a)
                 accepted = true;
                 rejected = false;
             } else {
-                double fac = SAFETY * pow(error_norm, -0.2);
-                if (!(fac > MIN_FACTOR)) fac = MIN_FACTOR;
+                // max(MIN_FACTOR, SAFETY * err^-0.2): the clamp is active above 4.5^5 = 1845 (and for NaN)
+                double fac = MIN_FACTOR;
+                if (error_norm < 1800.0) {
+                    fac = SAFETY * pow_m02(error_norm);
+                    if (!(fac > MIN_FACTOR)) fac = MIN_FACTOR;
+                }
                 h_abs *= fac;
                 rejected = true;
                 n_rej++;
@@ -756,6 +900,20 @@ __global__ void pgr_eval_kernel(EnvDev env, const double* x, const double* y, in
     unsigned g = C.events(x[k], y[3 * k + 1], y[3 * k + 2], c);
     for (int q = 0; q < 4; q++) o[5 + q] = ((g >> q) & 1u) ? 1.0 : -1.0;
     o[9] = C.bathy(x[k]);
+}
+
+// accuracy probe for the arithmetic building blocks (tests only)
+__global__ void pgr_math_kernel(const double* a, const double* b, int64_t M, double* out)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= M) return;
+    double* o = out + 6 * k;
+    o[0] = fdiv(a[k], b[k]);
+    o[1] = frcp(b[k]);
+    o[2] = frsqrt(b[k]);
+    o[3] = fsqrt(b[k]);
+    o[4] = pow_m02(b[k]);
+    o[5] = min_step_of(a[k]);
 }
 
 // ====================================================================================
@@ -952,6 +1110,13 @@ extern "C" int pgr_env_create(pgr_env** out, int device, const double* cin, cons
     d.row_stride = indep ? 0 : (int)nz;
     d.z_uniform = exactly_uniform(zin, nz, d.z0, d.dz);
     d.inv_dz = d.z_uniform ? 1.0 / d.dz : 0.0;
+    d.z_pow2 = 0;
+    if (d.z_uniform) {
+        int ex = 0;
+        bool pow2 = (std::frexp(d.dz, &ex) == 0.5);
+        for (int64_t j = 0; j + 1 < nz && pow2; j++) pow2 = (zin[j + 1] - zin[j] == d.dz);
+        d.z_pow2 = pow2 ? 1 : 0;
+    }
     d.r_uniform = exactly_uniform(rin, nr, d.r0, d.dr);
     d.inv_dr = d.r_uniform ? 1.0 / d.dr : 0.0;
     d.b_uniform = exactly_uniform(depth_ranges, nb, d.b0, d.db);
@@ -1105,6 +1270,23 @@ extern "C" int pgr_shoot_fan(pgr_env* env, const double* y0, int64_t N, double s
     HIPCHK(hipMemcpy(status, dst.p, N * 4, hipMemcpyDeviceToHost));
     if (n_steps) HIPCHK(hipMemcpy(n_steps, dn1.p, N * 4, hipMemcpyDeviceToHost));
     if (n_rej) HIPCHK(hipMemcpy(n_rej, dn2.p, N * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int pgr_debug_math(const double* a, const double* b, int64_t M, double* out6)
+{
+    if (!a || !b || !out6 || M <= 0) return fail("pgr_debug_math: bad argument");
+    struct Buf { void* p = nullptr; ~Buf() { if (p) (void)hipFree(p); } } da, db, dout;
+    HIPCHK(hipMalloc(&da.p, M * 8));
+    HIPCHK(hipMalloc(&db.p, M * 8));
+    HIPCHK(hipMalloc(&dout.p, M * 48));
+    HIPCHK(hipMemcpy(da.p, a, M * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(db.p, b, M * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(pgr_math_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, 0,
+                       (const double*)da.p, (const double*)db.p, M, (double*)dout.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out6, dout.p, M * 48, hipMemcpyDeviceToHost));
     return 0;
 }
 

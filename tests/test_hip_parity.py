@@ -283,3 +283,22 @@ def test_full_size_config1_properties(lib):
     assert np.abs(H_end / H0 - 1).max() < 1e-4
     total = int(a["n_steps"][ok].sum())
     assert 1.2e8 < total < 1.7e8
+
+
+def test_arithmetic_building_blocks(lib):
+    """The kernel's divide / sqrt expansions must be correctly rounded on the operand ranges
+    that occur (they replace the compiler's IEEE expansions), err^-0.2 within 2 ulp, and
+    10*ulp(t) exact."""
+    rng = np.random.default_rng(0)
+    M = 1_000_000
+    a = rng.uniform(-1e4, 1e4, M) * 10.0 ** rng.integers(-8, 8, M)
+    b = rng.uniform(0.1, 10, M) * 10.0 ** rng.integers(-12, 12, M)
+    b[:300000] = 10 ** rng.uniform(np.log10(5e-6), np.log10(1800), 300000)
+    o = lib.debug_math(a, b)
+    assert np.array_equal(o[:, 0], a / b)
+    assert np.array_equal(o[:, 1], 1 / b)
+    assert np.array_equal(o[:, 2], 1 / np.sqrt(b))
+    assert np.array_equal(o[:, 3], np.sqrt(b))
+    ref = np.power(b[:300000].astype(np.longdouble), np.longdouble(-0.2)).astype(np.float64)
+    assert (np.abs(o[:300000, 4] - ref) / np.spacing(ref)).max() <= 2.0
+    assert np.array_equal(o[:, 5], 10 * np.abs(np.nextafter(a, np.inf) - a))
