@@ -46,6 +46,8 @@ struct EnvDev {
     int z_uniform, r_uniform, b_uniform;  // grid[j] == g0 + j*dg bitwise (host verified)
     int beta_zero;  // all bottom angles are 0 -> the cubic is identically 0
     int z_pow2;     // z_uniform, dz a power of two and every zin[j+1]-zin[j] == dz bitwise
+    int z_simple;   // z_pow2 and zin[0] == 0: zin[j] == j*dz
+    double b_zmin, b_xlo, b_xhi;  // min(depths) - 1 m and the bathymetry table's range span
     double z0, dz, inv_dz;
     double r0, dr, inv_dr;
     double b0, db, inv_db;
@@ -121,7 +123,10 @@ __device__ __forceinline__ double frcp(double b)
 __device__ __forceinline__ double fdiv(double a, double b)
 {
 #if PGR_FAST
-    double y = frcp(b);
+    // one Newton step is enough before the correction (v_rcp_f64 is good to 4.6e-8)
+    double y = __builtin_amdgcn_rcp(b);
+    double e = fma(-b, y, 1.0);
+    y = fma(y, e, y);
     double q = a * y;
     double r = fma(-q, b, a);
     return fma(r, y, q);
@@ -155,9 +160,11 @@ __device__ __forceinline__ double fsqrt(double x)
 {
 #if PGR_FAST
     if (!(x > 0)) return (x == 0) ? 0.0 : sqrt(x);
-    double y = frsqrt_raw(x);
+    double y = __builtin_amdgcn_rsq(x);  // good to 5.2e-8: one Newton step, then the residual
+    double e = fma(-x * y, y, 1.0);
+    y = fma(y * 0.5, e, y);
     double g = x * y;
-    double d = fma(-g, g, x);  // residual
+    double d = fma(-g, g, x);
     return fma(d * 0.5, y, g);
 #else
     return sqrt(x);
@@ -235,11 +242,21 @@ __device__ __forceinline__ int cell_search(double q, const double* __restrict__ 
 // ------------------------------------------------------------------------------------
 // per-kernel context: where table nodes come from
 // ------------------------------------------------------------------------------------
-template <bool LDS_TAB>
+// ZS ("z simple"): zin[j] == j*dz bitwise with dz a power of two and zin[0] == 0 (e.g. the
+// reference's default np.arange(0, 6000, 1)): the cell index is ceil(z/dz) - 1 and the weight an
+// exact scaling -- no search, no fix-up, no division.
+template <bool LDS_TAB, bool ZS>
 struct Ctx {
     const EnvDev& e;
     const double2* lds;  // LDS copy of the (single) depth profile when LDS_TAB
-    __device__ __forceinline__ Ctx(const EnvDev& e_, const double2* l) : e(e_), lds(l) {}
+    // per-lane caches: x only moves forward, so the range cell (and the bathymetry cell under
+    // the ray) changes once every ~10 km; keep its edges and the reciprocal of its width
+    mutable double r_lo, r_hi, r_yden;
+    mutable int r_i;
+    __device__ __forceinline__ Ctx(const EnvDev& e_, const double2* l) : e(e_), lds(l)
+    {
+        r_lo = 1.0; r_hi = 0.0; r_yden = 1.0; r_i = 0;  // empty interval: first use refills
+    }
 
     __device__ __forceinline__ int cell_z(double z, double& zj, double& zj1) const
     {
@@ -269,16 +286,39 @@ struct Ctx {
         }
         return i;
     }
+    // wx = (x - rin[i]) / (rin[i+1] - rin[i]) through the cached cell
+    __device__ __forceinline__ double weight_r(double x, int& i) const
+    {
+        if (!(x > r_lo && x <= r_hi)) {
+            double ri, ri1;
+            r_i = cell_r(x, ri, ri1);
+            r_lo = ri; r_hi = ri1;
+            r_yden = frcp(ri1 - ri);
+        }
+        i = r_i;
+#if PGR_FAST
+        return fdiv_y(x - r_lo, r_hi - r_lo, r_yden);
+#else
+        return (x - r_lo) / (r_hi - r_lo);
+#endif
+    }
 
     // bilinear c and dc/dz at (x, z): REF/integration_processes.py:101-174, both tables at once
     __device__ __forceinline__ void lookup(double x, double z, double& c, double& cp) const
     {
-        double ri, ri1, zj, zj1;
-        int i = cell_r(x, ri, ri1);
-        int j = cell_z(z, zj, zj1);
-        double wx = fdiv(x - ri, ri1 - ri);
-        // every cell is exactly dz wide and dz is a power of two: the division is an exact scaling
-        double wy = e.z_pow2 ? (z - zj) * e.inv_dz : fdiv(z - zj, zj1 - zj);
+        int i, j;
+        double wx = weight_r(x, i);
+        double wy;
+        if (ZS) {
+            double t = z * e.inv_dz;                     // exact
+            j = min(max((int)ceil(fmin(fmax(t, -1.0), (double)e.nz)) - 1, 0), e.nz - 2);
+            wy = (z - (double)j * e.dz) * e.inv_dz;      // (z - zin[j]) / dz, exact scaling
+        } else {
+            double zj, zj1;
+            j = cell_z(z, zj, zj1);
+            // every cell exactly dz wide and dz a power of two: the division is an exact scaling
+            wy = e.z_pow2 ? (z - zj) * e.inv_dz : fdiv(z - zj, zj1 - zj);
+        }
         double2 v00, v01, v10, v11;
         if (LDS_TAB) {
             v00 = lds[j];
@@ -344,7 +384,9 @@ struct Ctx {
         double pc = pz * c;
         unsigned g = 0;
         if ((z < 0) && (pc < 0) && (pc >= -1.0)) g |= 1u;
-        if ((pc > 0) && (pc <= 1.0)) {
+        // bottom: z > bathy(x) is impossible while z is above the shallowest bathymetry node
+        // (minus a margin for the interpolation's rounding) and x is inside the bathymetry table
+        if ((pc > 0) && (pc <= 1.0) && !(z < e.b_zmin && x >= e.b_xlo && x <= e.b_xhi)) {
             if (z > bathy(x)) g |= 2u;
         }
         if (fabs(pc) > 0.9999999998 && fabs(pc) <= 1.0) {
@@ -402,10 +444,11 @@ __device__ __forceinline__ double rms3(double a, double b, double c)
 
 // quartic dense output of one accepted step: Q = K.T @ P (SCIPY/rk.py:178-180, 393-404)
 struct Dense {
-    double t_old, h;
-    double y0, y1, y2;
+    double h;
     double q[3][4];
-    __device__ __forceinline__ void eval(double t, double& o0, double& o1, double& o2) const
+    // (t_old, y_old) are the lane's still-uncommitted (t, y): passed in, not duplicated
+    __device__ __forceinline__ void eval(double t_old, double y0, double y1, double y2, double t,
+                                         double& o0, double& o1, double& o2) const
     {
         // SCIPY/rk.py:560-574: x = (t - t_old)/h ; p = cumprod ; y = h * (Q @ p) + y_old
         double x = fdiv(t - t_old, h);
@@ -485,7 +528,7 @@ struct SaveGrid {
 // lanes together (when `park_lanes` lanes wait, or the oldest has waited `park_trips` trips, or
 // nobody else can step).  Per-ray arithmetic is unchanged by when the service runs.
 // ------------------------------------------------------------------------------------
-template <bool LDS_TAB>
+template <bool LDS_TAB, bool ZS>
 __global__ void __launch_bounds__(512)
 pgr_fan_kernel(EnvDev env, FanArgs a)
 {
@@ -495,7 +538,7 @@ pgr_fan_kernel(EnvDev env, FanArgs a)
         for (int j = threadIdx.x; j < env.nz; j += blockDim.x) lds_tab[j] = env.tab[j];
         __syncthreads();
     }
-    const Ctx<LDS_TAB> C(env, lds_tab);
+    const Ctx<LDS_TAB, ZS> C(env, lds_tab);
     // waves are dealt to workgroups round-robin (wave w of block b = global wave w*grid + b):
     // neighbouring launch angles cost alike, so a strided deal balances the CUs
     const int64_t gwave = (int64_t)(threadIdx.x >> 6) * gridDim.x + blockIdx.x;
@@ -524,14 +567,15 @@ pgr_fan_kernel(EnvDev env, FanArgs a)
     double rnext = 0;
     // dense output of the step a parked lane is holding (t_old = t, y_old = y are still live)
     Dense D;
-    D.t_old = 0; D.h = 1; D.y0 = D.y1 = D.y2 = 0;
+    D.h = 1;
     for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) D.q[i][j] = 0;
     double pk_tnew = 0;
     unsigned pk_active = 0;
     int waited = 0;
-    double* Tp = save ? a.T + ray * a.stride_ray : nullptr;
-    double* Zp = save ? a.Z + ray * a.stride_ray : nullptr;
-    double* Pp = save ? a.P + ray * a.stride_ray : nullptr;
+    const int64_t out_off = ray * a.stride_ray;
+#define Tp (a.T + out_off)
+#define Zp (a.Z + out_off)
+#define Pp (a.P + out_off)
 
     while (__any(status == RUNNING)) {
         const bool run = (status == RUNNING);
@@ -589,10 +633,10 @@ pgr_fan_kernel(EnvDev env, FanArgs a)
                             double delta = (4 * DBL_EPSILON + 4 * DBL_EPSILON * fabs(xs)) / 2;
                             double xa = fmax(xs - delta, t), xb = fmin(xs + delta, t_new);
                             double ez0, ez1, ez2, ec, ecp;
-                            D.eval(xa, ez0, ez1, ez2);
+                            D.eval(t, y0, y1, y2, xa, ez0, ez1, ez2);
                             C.lookup(xa, ez1, ec, ecp);
                             bool ga = (C.events(xa, ez1, ez2, ec) & active) != 0;
-                            D.eval(xb, ez0, ez1, ez2);
+                            D.eval(t, y0, y1, y2, xb, ez0, ez1, ez2);
                             C.lookup(xb, ez1, ec, ecp);
                             bool gb = (C.events(xb, ez1, ez2, ec) & active) != 0;
                             if (!ga && gb) { best = xb; ev = bottom ? 1 : 0; }
@@ -607,10 +651,10 @@ pgr_fan_kernel(EnvDev env, FanArgs a)
                             if (!(active & (1u << k))) continue;
                             double xpre = t, xcur = t_new, xblk = 0;
                             double ez0, ez1, ez2, ec, ecp;
-                            D.eval(xpre, ez0, ez1, ez2);
+                            D.eval(t, y0, y1, y2, xpre, ez0, ez1, ez2);
                             C.lookup(xpre, ez1, ec, ecp);
                             bool fpre = (C.events(xpre, ez1, ez2, ec) >> k) & 1u;
-                            D.eval(xcur, ez0, ez1, ez2);
+                            D.eval(t, y0, y1, y2, xcur, ez0, ez1, ez2);
                             C.lookup(xcur, ez1, ec, ecp);
                             bool fcur = (C.events(xcur, ez1, ez2, ec) >> k) & 1u;
                             if (fpre == fcur) { status = PGR_RAY_EVENT_ERROR; break; }
@@ -623,7 +667,7 @@ pgr_fan_kernel(EnvDev env, FanArgs a)
                                 fpre = fcur;
                                 if (fabs(sbis) > delta) xcur += sbis;
                                 else xcur += (sbis > 0 ? delta : -delta);
-                                D.eval(xcur, ez0, ez1, ez2);
+                                D.eval(t, y0, y1, y2, xcur, ez0, ez1, ez2);
                                 C.lookup(xcur, ez1, ec, ecp);
                                 fcur = (C.events(xcur, ez1, ez2, ec) >> k) & 1u;
                             }
@@ -636,7 +680,7 @@ pgr_fan_kernel(EnvDev env, FanArgs a)
                         if (save) {
                             while (jnext < S - 1 && rnext <= t_end) {
                                 double o0, o1, o2;
-                                D.eval(rnext, o0, o1, o2);
+                                D.eval(t, y0, y1, y2, rnext, o0, o1, o2);
                                 Tp[(int64_t)jnext * a.stride_smp] = o0;
                                 Zp[(int64_t)jnext * a.stride_smp] = o1;
                                 Pp[(int64_t)jnext * a.stride_smp] = o2;
@@ -647,7 +691,7 @@ pgr_fan_kernel(EnvDev env, FanArgs a)
                         // terminal event: t = root, y = sol(root) (SCIPY/ivp.py:689-692), then the
                         // bounce logic of REF/launch_rays.py:432-480
                         double r0, r1, r2;
-                        D.eval(t_end, r0, r1, r2);
+                        D.eval(t, y0, y1, y2, t_end, r0, r1, r2);
                         t = t_end; y0 = r0; y1 = r1; y2 = r2;
                         if (ev == 2) status = PGR_RAY_VERTICAL;
                         else if (ev == 3) status = PGR_RAY_BBOX;
@@ -814,7 +858,7 @@ pgr_fan_kernel(EnvDev env, FanArgs a)
                 g = g_new;
                 bool want_samples = save && (jnext < S - 1) && (rnext <= t_new);
                 if (active || want_samples) {
-                    D.t_old = t; D.h = h; D.y0 = y0; D.y1 = y1; D.y2 = y2;
+                    D.h = h;
                     D.q[0][0] = PQ(f0, k30, k40, k50, k60, k70, 0);
                     D.q[0][1] = PQ(f0, k30, k40, k50, k60, k70, 1);
                     D.q[0][2] = PQ(f0, k30, k40, k50, k60, k70, 2);
@@ -839,7 +883,7 @@ pgr_fan_kernel(EnvDev env, FanArgs a)
                     if (want_samples) {
                         while (jnext < S - 1 && rnext <= t_new) {
                             double o0, o1, o2;
-                            D.eval(rnext, o0, o1, o2);
+                            D.eval(t, y0, y1, y2, rnext, o0, o1, o2);
                             Tp[(int64_t)jnext * a.stride_smp] = o0;
                             Zp[(int64_t)jnext * a.stride_smp] = o1;
                             Pp[(int64_t)jnext * a.stride_smp] = o2;
@@ -884,6 +928,9 @@ pgr_fan_kernel(EnvDev env, FanArgs a)
         if (a.n_steps) a.n_steps[ray] = n_steps;
         if (a.n_rej) a.n_rej[ray] = n_rej;
     }
+#undef Tp
+#undef Zp
+#undef Pp
 }
 
 // unit-level evaluation of a1-a8 at arbitrary points (parity tests)
@@ -891,7 +938,7 @@ __global__ void pgr_eval_kernel(EnvDev env, const double* x, const double* y, in
 {
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= M) return;
-    const Ctx<false> C(env, nullptr);
+    const Ctx<false, false> C(env, nullptr);
     double d0, d1, d2, c;
     C.rhs(x[k], y[3 * k + 1], y[3 * k + 2], d0, d1, d2, c);
     double* o = out + 10 * k;
@@ -907,13 +954,33 @@ __global__ void pgr_math_kernel(const double* a, const double* b, int64_t M, dou
 {
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= M) return;
+#ifdef PGR_PROBE_EXTRA
+    double* o = out + 12 * k;
+#else
     double* o = out + 6 * k;
+#endif
     o[0] = fdiv(a[k], b[k]);
     o[1] = frcp(b[k]);
     o[2] = frsqrt(b[k]);
     o[3] = fsqrt(b[k]);
     o[4] = pow_m02(b[k]);
     o[5] = min_step_of(a[k]);
+#ifdef PGR_PROBE_EXTRA
+    {   // experiments: raw instruction accuracy and 1-Newton variants
+        double y = __builtin_amdgcn_rcp(b[k]);
+        o[6] = y;
+        double e = fma(-b[k], y, 1.0); y = fma(y, e, y);
+        double q = a[k] * y; double r = fma(-q, b[k], a[k]); o[7] = fma(r, y, q);
+        double s = __builtin_amdgcn_rsq(b[k]);
+        o[8] = s;
+        double e2 = fma(-b[k] * s, s, 1.0); s = fma(s * 0.5, e2, s);
+        double g = b[k] * s; double d = fma(-g, g, b[k]); o[9] = fma(d * 0.5, s, g);
+        // reciprocal with one Newton step then a correction step of its own
+        double y1 = __builtin_amdgcn_rcp(b[k]); double e1 = fma(-b[k], y1, 1.0); y1 = fma(y1, e1, y1);
+        double r1 = fma(-b[k], y1, 1.0); o[10] = fma(r1, y1, y1);
+        o[11] = 0;
+    }
+#endif
 }
 
 // ====================================================================================
@@ -1117,6 +1184,12 @@ extern "C" int pgr_env_create(pgr_env** out, int device, const double* cin, cons
         for (int64_t j = 0; j + 1 < nz && pow2; j++) pow2 = (zin[j + 1] - zin[j] == d.dz);
         d.z_pow2 = pow2 ? 1 : 0;
     }
+    d.z_simple = (d.z_pow2 && d.z0 == 0.0) ? 1 : 0;
+    d.b_zmin = depths[0];
+    for (int64_t i = 1; i < nb; i++) d.b_zmin = depths[i] < d.b_zmin ? depths[i] : d.b_zmin;
+    d.b_zmin -= 1.0;
+    d.b_xlo = depth_ranges[0];
+    d.b_xhi = depth_ranges[nb - 1];
     d.r_uniform = exactly_uniform(rin, nr, d.r0, d.dr);
     d.inv_dr = d.r_uniform ? 1.0 / d.dr : 0.0;
     d.b_uniform = exactly_uniform(depth_ranges, nb, d.b0, d.db);
@@ -1195,14 +1268,23 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
         int threads = wpb * 64;
         int64_t blocks = (N + threads - 1) / threads;
         size_t lds = (size_t)env->d.nz * sizeof(double2);
-        HIPCHK(hipFuncSetAttribute((const void*)pgr_fan_kernel<true>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(pgr_fan_kernel<true>, dim3((unsigned)blocks), dim3(threads), lds, st, env->d, a);
+        if (env->d.z_simple) {
+            HIPCHK(hipFuncSetAttribute((const void*)pgr_fan_kernel<true, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((pgr_fan_kernel<true, true>), dim3((unsigned)blocks), dim3(threads), lds, st, env->d, a);
+        } else {
+            HIPCHK(hipFuncSetAttribute((const void*)pgr_fan_kernel<true, false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((pgr_fan_kernel<true, false>), dim3((unsigned)blocks), dim3(threads), lds, st, env->d, a);
+        }
     } else {
         int wpb = g_waves_per_block ? g_waves_per_block : 4;
         int threads = wpb * 64;
         int64_t blocks = (N + threads - 1) / threads;
-        hipLaunchKernelGGL(pgr_fan_kernel<false>, dim3((unsigned)blocks), dim3(threads), 0, st, env->d, a);
+        if (env->d.z_simple)
+            hipLaunchKernelGGL((pgr_fan_kernel<false, true>), dim3((unsigned)blocks), dim3(threads), 0, st, env->d, a);
+        else
+            hipLaunchKernelGGL((pgr_fan_kernel<false, false>), dim3((unsigned)blocks), dim3(threads), 0, st, env->d, a);
     }
     HIPCHK(hipGetLastError());
     return 0;
