@@ -170,13 +170,25 @@ __device__ __forceinline__ double fsqrt(double x)
     return sqrt(x);
 #endif
 }
-// the reference's `1 / np.sqrt(arg)`: RN(1 / RN(sqrt x))
+// the reference's `1 / np.sqrt(arg)`: RN(1 / RN(sqrt x)).  The refined rsq is an excellent seed
+// for 1/s (s = RN(sqrt x)): one correction step lands on the correctly rounded reciprocal.
 __device__ __forceinline__ double frsqrt(double x)
 {
 #ifdef PGR_FMA
     return frsqrt_raw(x);
+#elif PGR_FAST
+    double y = __builtin_amdgcn_rsq(x);
+    double e = fma(-x * y, y, 1.0);
+    y = fma(y * 0.5, e, y);
+    double g = x * y;
+    double d = fma(-g, g, x);
+    double s = fma(d * 0.5, y, g);   // RN(sqrt x)
+    double r = fma(-s, y, 1.0);      // y ~ 1/s to ~2e-15
+    y = fma(y, r, y);
+    r = fma(-s, y, 1.0);
+    return fma(y, r, y);             // RN(1/s)
 #else
-    return frcp(fsqrt(x));
+    return 1 / sqrt(x);
 #endif
 }
 // err^(-1/5) for err in [1e-7, 1e4]
@@ -311,7 +323,8 @@ struct Ctx {
         double wy;
         if (ZS) {
             double t = z * e.inv_dz;                     // exact
-            j = min(max((int)ceil(fmin(fmax(t, -1.0), (double)e.nz)) - 1, 0), e.nz - 2);
+            // v_cvt_i32_f64 saturates and maps NaN to 0: no clamp needed before the conversion
+            j = min(max((int)ceil(t) - 1, 0), e.nz - 2);
             wy = (z - (double)j * e.dz) * e.inv_dz;      // (z - zin[j]) / dz, exact scaling
         } else {
             double zj, zj1;
@@ -436,7 +449,8 @@ __device__ __forceinline__ double rms3(double a, double b, double c)
 {
     // np.linalg.norm(x) / x.size ** 0.5, SCIPY/common.py:63-65
 #if PGR_FAST
-    return fdiv(fsqrt(a * a + b * b + c * c), 1.7320508075688772);
+    // x / 3**0.5 with the (correctly rounded) reciprocal of the constant as Markstein seed
+    return fdiv_y(fsqrt(a * a + b * b + c * c), 1.7320508075688772, 0.57735026918962584);
 #else
     return sqrt(a * a + b * b + c * c) / 1.7320508075688772;
 #endif
