@@ -67,7 +67,8 @@ class RayFan:
             return
         ray_ids = np.sum(np.diff(np.sign(self.ps)) != 0, axis=1) * (np.sign(self.thetas))
         b_mask = (self.n_botts == 0) & (self.n_surfs == 0)
-        self.ray_ids = np.array([str(i) if b else f"{i}b" for i, b in zip(ray_ids, b_mask)])
+        txt = ray_ids.astype(str)  # same text as str(np.float64): '-3.0', '0.0', ...
+        self.ray_ids = np.where(b_mask, txt, np.char.add(txt, "b"))
 
     def __len__(self):
         return len(self.thetas)
