@@ -47,7 +47,7 @@ def munk_tables(r_max, nr=100):
     return env, _unpack_envi(env, flatearth=False)
 
 
-def cpu_baseline(arrs, n_rays=2048):
+def cpu_baseline(arrs, n_rays=12500):
     """CPU oracle (C port of the reference integrator, OpenMP over rays) on a bounded sample:
     every (100000/n_rays)-th ray of the same fan, full 1000 km, end-state + trajectories."""
     import oracle

@@ -57,11 +57,29 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).  Two
+    HIP runtimes in one process do not work (the second one finds no GPUs, and a torch stream
+    handed to the other runtime is undefined behaviour), so when torch is installed its copy is
+    loaded first and libpgr_hip.so's DT_NEEDED libamdhip64.so.7 resolves to it -- whichever of
+    torch / pygenray_amd is imported first.  Without torch the system runtime is used."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is not None and spec.origin:
+            p = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+            if os.path.exists(p):
+                ctypes.CDLL(p, mode=ctypes.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def load():
     """Load libpgr_hip.so; raise loudly if it is absent (no fallback)."""
     global _lib
     if _lib is not None:
         return _lib
+    _preload_torch_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise PgrError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run "

@@ -302,3 +302,81 @@ def test_arithmetic_building_blocks(lib):
     ref = np.power(b[:300000].astype(np.longdouble), np.longdouble(-0.2)).astype(np.float64)
     assert (np.abs(o[:300000, 4] - ref) / np.spacing(ref)).max() <= 2.0
     assert np.array_equal(o[:, 5], 10 * np.abs(np.nextafter(a, np.inf) - a))
+
+
+def test_exact_bisection_flag_agrees_with_default_locator(lib):
+    """PGR_EXACT_BISECTION runs brentq's ~42-step bisection on the +-1 event; the default
+    locator (Newton on the quartic + verified bracket of brentq's final width) must land on the
+    same roots: identical bounce counts and end states within the parity policy."""
+    arrs = munk_arrays(300e3)
+    y0 = y0_for(oracle, arrs, 1000.0, 0.0, np.linspace(15.0, 20.0, 128))
+    env = lib.EnvHandle(*arrs)
+    a = env.shoot_fan(y0, 0.0, 300e3, 31)
+    b = env.shoot_fan(y0, 0.0, 300e3, 31, exact_bisection=True)
+    o = oracle.shoot_fan(*arrs, y0, 0.0, 300e3, 31)
+    assert (o["n_bott"] + o["n_surf"]).min() >= 5
+    for g in (a, b):
+        assert np.array_equal(g["n_bott"], o["n_bott"]) and np.array_equal(g["n_surf"], o["n_surf"])
+    noise = oracle_selfnoise(oracle, arrs, y0, 0.0, 300e3, 31)
+    assert_fan_parity(a, o, noise_runs=noise, scales=(5000.0, 205.0, 1 / 1500.0), label="default locator")
+    assert_fan_parity(b, o, noise_runs=noise, scales=(5000.0, 205.0, 1 / 1500.0), label="exact bisection")
+    # the two locators agree with each other far better than either needs to with the oracle
+    d = np.abs(a["end"][:, 1] - b["end"][:, 1])
+    assert np.median(d) < 1e-6
+
+
+def test_edge_shapes_and_inputs(lib):
+    arrs = munk_arrays(50e3, nr=12)
+    env = lib.EnvHandle(*arrs)
+    y1 = y0_for(oracle, arrs, 800.0, 0.0, [3.0])
+    # one ray, one / two save points
+    for S in (1, 2, 3):
+        g = env.shoot_fan(y1, 0.0, 50e3, S)
+        o = oracle.shoot_fan(*arrs, y1, 0.0, 50e3, S)
+        assert g["T"].shape == (1, S) and g["status"][0] == 0
+        np.testing.assert_allclose(g["z"], o["z"], rtol=0, atol=5e-5)
+        assert g["z"][0, -1] == g["end"][0, 1]
+    # exactly one wave, one wave + 1, and a ragged multi-block fan give the same per-ray results
+    th = np.linspace(-18, 18, 193)
+    y = y0_for(oracle, arrs, 800.0, 0.0, th)
+    full = env.shoot_fan(y, 0.0, 50e3, 11)
+    for n in (64, 65, 129):
+        part = env.shoot_fan(y[:n], 0.0, 50e3, 11)
+        assert np.array_equal(part["z"], full["z"][:n]) and np.array_equal(part["n_steps"], full["n_steps"][:n])
+    # a NaN / inf initial state cannot hang the kernel: the ray is dropped with a status
+    bad = y[:4].copy()
+    bad[0, 2] = np.nan
+    bad[1, 1] = np.inf
+    bad[2, 2] = 1.0          # |p c| >> 1: clamp path (Q8), then bbox / step failure
+    g = env.shoot_fan(bad, 0.0, 50e3, 5, max_steps=5000)
+    assert np.all(g["status"][:3] != 0) and g["status"][3] == 0
+    assert np.all(np.isnan(g["z"][:3])) and np.all(np.isfinite(g["z"][3]))
+    # source beyond the table's last range column: bounding-box event fires immediately
+    g = env.shoot_fan(y[:2], 49e3, 80e3, 5)
+    assert np.all(g["status"] == 2)
+    # not terminate_backwards: a backwards bounce continues (reference default is True)
+    arrs2 = munk_arrays(50e3, nr=20, z=np.linspace(0, 6000, 601))
+    arrs2[4] = np.where(arrs2[2] > 20e3, 1000.0, 5000.0).astype(float)
+    arrs2[6] = np.degrees(np.arctan(np.gradient(arrs2[4], arrs2[5])))
+    yb = y0_for(oracle, arrs2, 500.0, 0.0, [12.0])
+    e2 = lib.EnvHandle(*arrs2)
+    assert e2.shoot_fan(yb, 0.0, 50e3, 5)["status"][0] == 3
+    g = e2.shoot_fan(yb, 0.0, 50e3, 5, terminate_backwards=False, max_steps=20000)
+    o = oracle.shoot_fan(*arrs2, yb, 0.0, 50e3, 5, terminate_backwards=False, max_steps=20000)
+    assert g["status"][0] == o["status"][0]
+
+
+def test_sharded_hip_compute_single_rank(lib):
+    """distributed.shoot_fan_sharded with the HIP compute callback (world size 1 here; the
+    collective itself is covered under gloo in tests/test_host.py)."""
+    import torch
+    from pygenray_amd.distributed import shoot_fan_sharded, hip_compute, arrival_time_histogram
+    arrs = munk_arrays(100e3)
+    y0 = y0_for(oracle, arrs, 1000.0, 0.0, np.linspace(-15, 15, 300))
+    env = lib.EnvHandle(*arrs)
+    end, nb, ns, st = shoot_fan_sharded(hip_compute(env, 0.0, 100e3), y0)
+    ref = env.shoot_fan(y0, 0.0, 100e3, 1, save=False)
+    assert np.array_equal(end.cpu().numpy(), ref["end"], equal_nan=True)
+    assert np.array_equal(nb.cpu().numpy(), ref["n_bott"]) and np.array_equal(st.cpu().numpy(), ref["status"])
+    h = arrival_time_histogram(end[:, 0], st, 32, 66.0, 68.0)
+    assert int(h.sum().item()) == int(((ref["status"] == 0) & (ref["end"][:, 0] >= 66) & (ref["end"][:, 0] <= 68)).sum())
