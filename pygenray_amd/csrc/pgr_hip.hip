@@ -873,15 +873,16 @@ pgr_fan_kernel(EnvDev env, FanArgs a)
                 bool want_samples = save && (jnext < S - 1) && (rnext <= t_new);
                 if (active || want_samples) {
                     D.h = h;
-                    D.q[0][0] = PQ(f0, k30, k40, k50, k60, k70, 0);
+                    // column 0 of P is e_1: K.T @ P[:, 0] = K1 exactly (the other terms are +0.0)
+                    D.q[0][0] = f0;
                     D.q[0][1] = PQ(f0, k30, k40, k50, k60, k70, 1);
                     D.q[0][2] = PQ(f0, k30, k40, k50, k60, k70, 2);
                     D.q[0][3] = PQ(f0, k30, k40, k50, k60, k70, 3);
-                    D.q[1][0] = PQ(f1, k31, k41, k51, k61, k71, 0);
+                    D.q[1][0] = f1;
                     D.q[1][1] = PQ(f1, k31, k41, k51, k61, k71, 1);
                     D.q[1][2] = PQ(f1, k31, k41, k51, k61, k71, 2);
                     D.q[1][3] = PQ(f1, k31, k41, k51, k61, k71, 3);
-                    D.q[2][0] = PQ(f2, k32, k42, k52, k62, k72, 0);
+                    D.q[2][0] = f2;
                     D.q[2][1] = PQ(f2, k32, k42, k52, k62, k72, 1);
                     D.q[2][2] = PQ(f2, k32, k42, k52, k62, k72, 2);
                     D.q[2][3] = PQ(f2, k32, k42, k52, k62, k72, 3);

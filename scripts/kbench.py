@@ -17,9 +17,12 @@ ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--modes", nargs="*", default=["nosave", "ray", "sample"])
 ap.add_argument("--slope", type=float, default=0.0, help="sofar slope -> range dependent")
 ap.add_argument("--S", type=int, default=1001)
+ap.add_argument("--lib", default=None)
 ap.add_argument("--park", type=int, nargs="*", default=[64, 64], help="pairs: lanes trips lanes trips ...")
 ap.add_argument("--exact", action="store_true")
 a = ap.parse_args()
+if a.lib:
+    _lib.LIB_PATH = os.path.abspath(a.lib)
 arrs = munk_arrays(a.km * 1e3, nr=(101 if a.slope else 100), sofar_slope=a.slope)
 env = _lib.EnvHandle(*arrs)
 theta = np.linspace(a.amin, a.amax, a.rays)
