@@ -52,6 +52,8 @@ extern "C" {
                                       np.linspace(source_range, receiver_range, S); the kernel then
                                       recomputes r_save[j] = j*step + start instead of loading it.
                                       The host entry sets/clears this bit itself after checking. */
+#define PGR_DEBUG_TRIPS 16u       /* diagnostics: n_rej[] receives, per wave, the number of main-loop
+                                      trips (lane 0) and of service phases (other lanes) instead */
 
 typedef struct pgr_env pgr_env; /* opaque: environment tables resident in HBM */
 

@@ -265,7 +265,14 @@ struct Ctx {
     // the ray) changes once every ~10 km; keep its edges and the reciprocal of its width
     mutable double r_lo, r_hi, r_yden;
     mutable int r_i;
-    __device__ __forceinline__ Ctx(const EnvDev& e_, const double2* l) : e(e_), lds(l)
+    // wave-uniform copies of the fields the step loop touches (kept in SGPRs; the rest of the
+    // descriptor is read from memory where it is needed)
+    const double h_inv_dz, h_dz, h_r0, h_dr, h_inv_dr;
+    const double* const h_rin;
+    const int h_nz, h_nr, h_r_uniform;
+    __device__ __forceinline__ Ctx(const EnvDev& e_, const double2* l)
+        : e(e_), lds(l), h_inv_dz(e_.inv_dz), h_dz(e_.dz), h_r0(e_.r0), h_dr(e_.dr),
+          h_inv_dr(e_.inv_dr), h_rin(e_.rin), h_nz(e_.nz), h_nr(e_.nr), h_r_uniform(e_.r_uniform)
     {
         r_lo = 1.0; r_hi = 0.0; r_yden = 1.0; r_i = 0;  // empty interval: first use refills
     }
@@ -287,14 +294,14 @@ struct Ctx {
     __device__ __forceinline__ int cell_r(double x, double& ri, double& ri1) const
     {
         int i;
-        if (e.r_uniform) {
-            i = cell_uniform(x, e.r0, e.dr, e.inv_dr, e.nr);
-            ri = grid_at(e.r0, e.dr, i);
-            ri1 = grid_at(e.r0, e.dr, i + 1);
+        if (h_r_uniform) {
+            i = cell_uniform(x, h_r0, h_dr, h_inv_dr, h_nr);
+            ri = grid_at(h_r0, h_dr, i);
+            ri1 = grid_at(h_r0, h_dr, i + 1);
         } else {
-            i = cell_search(x, e.rin, e.nr);
-            ri = e.rin[i];
-            ri1 = e.rin[i + 1];
+            i = cell_search(x, h_rin, h_nr);
+            ri = h_rin[i];
+            ri1 = h_rin[i + 1];
         }
         return i;
     }
@@ -322,10 +329,10 @@ struct Ctx {
         double wx = weight_r(x, i);
         double wy;
         if (ZS) {
-            double t = z * e.inv_dz;                     // exact
+            double t = z * h_inv_dz;                     // exact
             // v_cvt_i32_f64 saturates and maps NaN to 0: no clamp needed before the conversion
-            j = min(max((int)ceil(t) - 1, 0), e.nz - 2);
-            wy = (z - (double)j * e.dz) * e.inv_dz;      // (z - zin[j]) / dz, exact scaling
+            j = min(max((int)ceil(t) - 1, 0), h_nz - 2);
+            wy = (z - (double)j * h_dz) * h_inv_dz;      // (z - zin[j]) / dz, exact scaling
         } else {
             double zj, zj1;
             j = cell_z(z, zj, zj1);
@@ -544,8 +551,12 @@ struct SaveGrid {
 // ------------------------------------------------------------------------------------
 template <bool LDS_TAB, bool ZS>
 __global__ void __launch_bounds__(512)
-pgr_fan_kernel(EnvDev env, FanArgs a)
+pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
 {
+    // the environment descriptor lives in device memory: its ~50 dwords would otherwise occupy
+    // half the wave's SGPRs as kernel arguments and push the Runge-Kutta tableau (60 fp64
+    // literals) into constant re-materialisation + SGPR spills inside the step loop
+    const EnvDev& env = *env_p;
     extern __shared__ double2 lds_tab[];
     if (LDS_TAB) {
         // stage the single depth profile {c, cp}[nz] into LDS (coalesced 16 B per lane)
@@ -586,12 +597,14 @@ pgr_fan_kernel(EnvDev env, FanArgs a)
     double pk_tnew = 0;
     unsigned pk_active = 0;
     int waited = 0;
+    int trips = 0, services = 0;  // diagnostics (PGR_DEBUG_TRIPS)
     const int64_t out_off = ray * a.stride_ray;
 #define Tp (a.T + out_off)
 #define Zp (a.Z + out_off)
 #define Pp (a.P + out_off)
 
     while (__any(status == RUNNING)) {
+        trips++;
         const bool run = (status == RUNNING);
         const bool pend = run && (parked || need_init);
         const unsigned long long pm = __ballot(pend);
@@ -600,6 +613,7 @@ pgr_fan_kernel(EnvDev env, FanArgs a)
             const bool nobody_steps = !__any(run && !pend);
             if (__popcll(pm) >= a.park_lanes || waited > a.park_trips || nobody_steps) {
                 waited = 0;
+                services++;
                 // =========================== SERVICE phase ===========================
                 if (pend && parked) {
                     parked = false;
@@ -941,7 +955,7 @@ pgr_fan_kernel(EnvDev env, FanArgs a)
         a.n_surf[ray] = ns;
         a.status[ray] = status;
         if (a.n_steps) a.n_steps[ray] = n_steps;
-        if (a.n_rej) a.n_rej[ray] = n_rej;
+        if (a.n_rej) a.n_rej[ray] = (a.flags & PGR_DEBUG_TRIPS) ? (((threadIdx.x & 63) == 0) ? trips : services) : n_rej;
     }
 #undef Tp
 #undef Zp
@@ -1003,7 +1017,7 @@ __global__ void pgr_math_kernel(const double* a, const double* b, int64_t M, dou
 // ====================================================================================
 static thread_local std::string g_err;
 static int g_waves_per_block = 0;
-static int g_park_lanes = 64, g_park_trips = 64;
+static int g_park_lanes = 64, g_park_trips = 16;
 
 static int fail(const std::string& m)
 {
@@ -1020,6 +1034,7 @@ static int fail(const std::string& m)
 struct pgr_env {
     int device = 0;
     EnvDev d{};
+    const EnvDev* d_dev = nullptr;  // device copy of `d` (kernel argument by pointer)
     int range_indep = 0;
     int lds_path = 0;
     std::vector<void*> allocs;
@@ -1216,6 +1231,7 @@ extern "C" int pgr_env_create(pgr_env** out, int device, const double* cin, cons
     d.zlo_tol = zin[0] - tol;
     d.rlo_tol = rin[0] - tol;
     d.rhi_tol = rin[nr - 1] + tol;
+    if (upload(e, &e->d, 1, &e->d_dev)) { pgr_env_destroy(e); return -1; }
     *out = e;
     return 0;
 }
@@ -1286,20 +1302,20 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
         if (env->d.z_simple) {
             HIPCHK(hipFuncSetAttribute((const void*)pgr_fan_kernel<true, true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((pgr_fan_kernel<true, true>), dim3((unsigned)blocks), dim3(threads), lds, st, env->d, a);
+            hipLaunchKernelGGL((pgr_fan_kernel<true, true>), dim3((unsigned)blocks), dim3(threads), lds, st, env->d_dev, a);
         } else {
             HIPCHK(hipFuncSetAttribute((const void*)pgr_fan_kernel<true, false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((pgr_fan_kernel<true, false>), dim3((unsigned)blocks), dim3(threads), lds, st, env->d, a);
+            hipLaunchKernelGGL((pgr_fan_kernel<true, false>), dim3((unsigned)blocks), dim3(threads), lds, st, env->d_dev, a);
         }
     } else {
         int wpb = g_waves_per_block ? g_waves_per_block : 4;
         int threads = wpb * 64;
         int64_t blocks = (N + threads - 1) / threads;
         if (env->d.z_simple)
-            hipLaunchKernelGGL((pgr_fan_kernel<false, true>), dim3((unsigned)blocks), dim3(threads), 0, st, env->d, a);
+            hipLaunchKernelGGL((pgr_fan_kernel<false, true>), dim3((unsigned)blocks), dim3(threads), 0, st, env->d_dev, a);
         else
-            hipLaunchKernelGGL((pgr_fan_kernel<false, false>), dim3((unsigned)blocks), dim3(threads), 0, st, env->d, a);
+            hipLaunchKernelGGL((pgr_fan_kernel<false, false>), dim3((unsigned)blocks), dim3(threads), 0, st, env->d_dev, a);
     }
     HIPCHK(hipGetLastError());
     return 0;

@@ -18,7 +18,7 @@ ap.add_argument("--modes", nargs="*", default=["nosave", "ray", "sample"])
 ap.add_argument("--slope", type=float, default=0.0, help="sofar slope -> range dependent")
 ap.add_argument("--S", type=int, default=1001)
 ap.add_argument("--lib", default=None)
-ap.add_argument("--park", type=int, nargs="*", default=[64, 64], help="pairs: lanes trips lanes trips ...")
+ap.add_argument("--park", type=int, nargs="*", default=[64, 16], help="pairs: lanes trips lanes trips ...")
 ap.add_argument("--exact", action="store_true")
 a = ap.parse_args()
 if a.lib:
