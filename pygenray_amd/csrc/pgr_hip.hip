@@ -1035,6 +1035,11 @@ struct pgr_env {
     int device = 0;
     EnvDev d{};
     const EnvDev* d_dev = nullptr;  // device copy of `d` (kernel argument by pointer)
+    // grow-only staging workspace of the host-pointer entry (kept while <= 256 MB so the many
+    // small fans of an eigenray search do not pay 11 hipMalloc/hipFree per call)
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    std::mutex ws_mutex;
     int range_indep = 0;
     int lds_path = 0;
     std::vector<void*> allocs;
@@ -1137,6 +1142,7 @@ extern "C" void pgr_env_destroy(pgr_env* env)
     if (!env) return;
     (void)hipSetDevice(env->device);
     for (void* p : env->allocs) (void)hipFree(p);
+    if (env->ws) (void)hipFree(env->ws);
     delete env;
 }
 
@@ -1342,13 +1348,28 @@ extern "C" int pgr_shoot_fan(pgr_env* env, const double* y0, int64_t N, double s
     bool save = (T != nullptr);
     if (save && (!z || !p || !r_save || S < 1)) return fail("pgr_shoot_fan: T, z, p, r_save, S go together");
     HIPCHK(hipSetDevice(env->device));
-    DevBuf dy0, dr, dT, dZ, dP, dE, dnb, dns, dst, dn1, dn2;
+    std::lock_guard<std::mutex> lock(env->ws_mutex);
     size_t ns_bytes = (size_t)N * (size_t)(save ? S : 0) * sizeof(double);
-    if (dy0.alloc(N * 3 * sizeof(double)) || dr.alloc((save ? S : 1) * sizeof(double)) ||
-        dT.alloc(ns_bytes) || dZ.alloc(ns_bytes) || dP.alloc(ns_bytes) ||
-        dE.alloc(N * 3 * sizeof(double)) || dnb.alloc(N * 4) || dns.alloc(N * 4) || dst.alloc(N * 4) ||
-        dn1.alloc(N * 4) || dn2.alloc(N * 4))
-        return fail("pgr_shoot_fan: device allocation failed");
+    // carve one workspace: y0, r_save, T, Z, P, end, 5 int arrays (256-byte aligned pieces)
+    const size_t sizes[11] = {(size_t)N * 24, (size_t)(save ? S : 1) * 8, ns_bytes, ns_bytes, ns_bytes,
+                              (size_t)N * 24, (size_t)N * 4, (size_t)N * 4, (size_t)N * 4, (size_t)N * 4,
+                              (size_t)N * 4};
+    size_t off[11], total = 0;
+    for (int k = 0; k < 11; k++) { off[k] = total; total += (sizes[k] + 255) & ~(size_t)255; }
+    if (total > env->ws_bytes) {
+        if (env->ws) (void)hipFree(env->ws);
+        env->ws = nullptr; env->ws_bytes = 0;
+        if (hipMalloc(&env->ws, total) != hipSuccess) { env->ws = nullptr; return fail("pgr_shoot_fan: device allocation failed"); }
+        env->ws_bytes = total;
+    }
+    struct Piece { void* p; } dy0{(char*)env->ws + off[0]}, dr{(char*)env->ws + off[1]}, dT{(char*)env->ws + off[2]},
+        dZ{(char*)env->ws + off[3]}, dP{(char*)env->ws + off[4]}, dE{(char*)env->ws + off[5]},
+        dnb{(char*)env->ws + off[6]}, dns{(char*)env->ws + off[7]}, dst{(char*)env->ws + off[8]},
+        dn1{(char*)env->ws + off[9]}, dn2{(char*)env->ws + off[10]};
+    struct Trim {  // give a large workspace back when the call ends
+        pgr_env* e;
+        ~Trim() { if (e->ws_bytes > ((size_t)256 << 20)) { (void)hipFree(e->ws); e->ws = nullptr; e->ws_bytes = 0; } }
+    } trim{env};
     HIPCHK(hipMemcpy(dy0.p, y0, N * 3 * sizeof(double), hipMemcpyHostToDevice));
     if (save) HIPCHK(hipMemcpy(dr.p, r_save, (size_t)S * sizeof(double), hipMemcpyHostToDevice));
     if (save) {

@@ -56,8 +56,18 @@ class RayFan:
         self.n_botts = np.asarray(n_botts)
         self.n_surfs = np.asarray(n_surfs)
         self.source_depths = np.asarray(source_depths)
-        self.compute_rayids()
+        self._ray_ids = None  # built on first access (a million-ray fan pays 0.2 s for the strings)
         return self
+
+    @property
+    def ray_ids(self):
+        if getattr(self, "_ray_ids", None) is None:
+            self.compute_rayids()
+        return self._ray_ids
+
+    @ray_ids.setter
+    def ray_ids(self, value):
+        self._ray_ids = value
 
     def compute_rayids(self):
         """Ray IDs: number of sign changes of p times sign(theta), 'b' suffix when the ray
