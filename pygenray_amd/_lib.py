@@ -234,3 +234,7 @@ def set_waves_per_block(w):
 
 def set_park(lanes, trips):
     check(load().pgr_set_park(int(lanes), int(trips)))
+
+
+def set_placement(on):
+    load().pgr_set_placement(int(bool(on)))

@@ -74,6 +74,7 @@ struct FanArgs {
     double save_step;  // linspace step when save_formula
     int save_formula;  // r_save[j] == j*save_step + x0 bitwise (host verified)
     int park_lanes, park_trips;  // service batching thresholds
+    const int* wave_map;  // [gridDim.x * waves_per_block] global wave of each slot, -1 = empty; null = strided deal
     int64_t max_steps;
     uint32_t flags;
 };
@@ -566,9 +567,11 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     const Ctx<LDS_TAB, ZS> C(env, lds_tab);
     // waves are dealt to workgroups round-robin (wave w of block b = global wave w*grid + b):
     // neighbouring launch angles cost alike, so a strided deal balances the CUs
-    const int64_t gwave = (int64_t)(threadIdx.x >> 6) * gridDim.x + blockIdx.x;
+    int64_t gwave = (int64_t)(threadIdx.x >> 6) * gridDim.x + blockIdx.x;
+    if (a.wave_map)  // cost-aware placement (pgr_wave_place): slot -> wave, -1 = slot left empty
+        gwave = a.wave_map[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)];
     const int64_t ray = gwave * 64 + (threadIdx.x & 63);
-    const bool valid = ray < a.N;
+    const bool valid = (gwave >= 0) && (ray < a.N);
     const double SAFETY = 0.9, MIN_FACTOR = 0.2, MAX_FACTOR = 10;
     const double rtol = a.rtol, atol = a.atol, t_bound = a.x1;
     const int S = a.S;
@@ -962,6 +965,65 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
 #undef Pp
 }
 
+// ------------------------------------------------------------------------------------
+// Cost-aware wave placement for fans of 1-2 waves per SIMD.
+//
+// With the LDS table there is one workgroup per CU, and a 1e5-ray fan is only ~1.5 waves per
+// SIMD: the launch lasts exactly as long as its slowest wave (the steepest rays: most steps,
+// most bounces), and that wave runs ~20 % slower when another wave shares its SIMD.  A
+// workgroup's waves go to the CU's four SIMDs cyclically, so waves k and k+4 of a workgroup
+// share a SIMD and, in a W-wave workgroup (4 < W <= 8), waves W-4..3 have a SIMD to themselves.
+// The grid is widened to every CU, which leaves spare slots; the most expensive waves (cost
+// proxy: the largest |p0| of the wave's rays -- steep rays bounce) get the natural lone slots,
+// the next ones get a pair slot whose partner slot stays empty, and the rest are paired
+// expensive-with-cheap.  Placement only changes WHERE a wave runs, never what it computes.
+// ------------------------------------------------------------------------------------
+__global__ void pgr_wave_cost(const double* __restrict__ y0, int64_t N, int n_waves, float* __restrict__ cost)
+{
+    int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (w >= n_waves) return;
+    int64_t ray = (int64_t)w * 64 + (threadIdx.x & 63);
+    float c = (ray < N) ? fabsf((float)y0[3 * ray + 2]) : 0.0f;
+    for (int o = 32; o > 0; o >>= 1) c = fmaxf(c, __shfl_xor(c, o));
+    if ((threadIdx.x & 63) == 0) cost[w] = c;
+}
+
+__global__ void __launch_bounds__(1024)
+pgr_wave_place(const float* __restrict__ cost, int n_waves, int B, int W, int* __restrict__ map)
+{
+    __shared__ float sc[2048];
+    for (int i = threadIdx.x; i < n_waves; i += blockDim.x) sc[i] = cost[i];
+    __syncthreads();
+    const int lone_per_block = 8 - W;                 // waves W-4 .. 3
+    const int n_lone = B * lone_per_block;
+    const int pairs = B * (W - 4);
+    int spare = B * W - n_waves;
+    int E = spare < pairs ? spare : pairs;            // pair slots run with an empty partner
+    const int P = pairs - E;                          // fully used pairs
+    for (int w = threadIdx.x; w < n_waves; w += blockDim.x) {
+        float c = sc[w];
+        int r = 0;                                    // rank by descending cost (ties: index)
+        for (int k = 0; k < n_waves; k++) r += (sc[k] > c) || (sc[k] == c && k < w);
+        int block, slot;
+        if (r < n_lone) {
+            block = r % B;
+            slot = (W - 4) + r / B;
+        } else if (r < n_lone + E) {
+            int q = r - n_lone;
+            block = q % B;
+            slot = q / B;                             // partner slot + 4 stays empty
+        } else {
+            int p = r - n_lone - E;                   // 0 .. 2P-1, descending cost
+            int first = p < P;
+            int pi = first ? p : (2 * P - 1 - p);     // expensive half meets cheap half
+            int q = E + pi;
+            block = q % B;
+            slot = q / B + (first ? 0 : 4);
+        }
+        map[block * W + slot] = w;
+    }
+}
+
 // unit-level evaluation of a1-a8 at arbitrary points (parity tests)
 __global__ void pgr_eval_kernel(EnvDev env, const double* x, const double* y, int64_t M, double* out)
 {
@@ -1018,6 +1080,7 @@ __global__ void pgr_math_kernel(const double* a, const double* b, int64_t M, dou
 static thread_local std::string g_err;
 static int g_waves_per_block = 0;
 static int g_park_lanes = 64, g_park_trips = 16;
+static int g_place = 1;  // cost-aware wave placement (pgr_set_placement)
 
 static int fail(const std::string& m)
 {
@@ -1040,6 +1103,10 @@ struct pgr_env {
     void* ws = nullptr;
     size_t ws_bytes = 0;
     std::mutex ws_mutex;
+    // ring of small buffers for the per-launch wave placement (cost[2048] + map[2048])
+    static constexpr int kPlaceRing = 8;
+    void* place_buf = nullptr;
+    int place_next = 0;
     int range_indep = 0;
     int lds_path = 0;
     std::vector<void*> allocs;
@@ -1061,6 +1128,12 @@ extern "C" int pgr_set_park(int lanes, int trips)
     if (lanes < 1 || lanes > 64 || trips < 0 || trips > 100000) return fail("pgr_set_park: lanes in [1,64], trips >= 0");
     g_park_lanes = lanes;
     g_park_trips = trips;
+    return 0;
+}
+
+extern "C" int pgr_set_placement(int on)
+{
+    g_place = on ? 1 : 0;
     return 0;
 }
 
@@ -1143,6 +1216,7 @@ extern "C" void pgr_env_destroy(pgr_env* env)
     (void)hipSetDevice(env->device);
     for (void* p : env->allocs) (void)hipFree(p);
     if (env->ws) (void)hipFree(env->ws);
+    if (env->place_buf) (void)hipFree(env->place_buf);
     delete env;
 }
 
@@ -1304,6 +1378,22 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
         }
         int threads = wpb * 64;
         int64_t blocks = (N + threads - 1) / threads;
+        // 1-2 waves per SIMD in a single round: widen the grid to every CU and place the waves
+        // by cost (see pgr_wave_place); otherwise the strided deal
+        if (g_waves_per_block == 0 && g_place && waves > 4 * (int64_t)env->num_cus &&
+            waves <= 8 * (int64_t)env->num_cus && env->num_cus * 8 <= 2048) {
+            int B = env->num_cus, W = wpb;  // W = ceil(waves / CUs) in 5..8
+            if (!env->place_buf)
+                HIPCHK(hipMalloc(&env->place_buf, (size_t)pgr_env::kPlaceRing * 2048 * 8));
+            char* slot = (char*)env->place_buf + (size_t)(env->place_next++ % pgr_env::kPlaceRing) * 2048 * 8;
+            float* cost = (float*)slot;
+            int* map = (int*)(slot + 2048 * 4);
+            HIPCHK(hipMemsetAsync(map, 0xFF, (size_t)B * W * sizeof(int), st));
+            hipLaunchKernelGGL(pgr_wave_cost, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, y0, N, (int)waves, cost);
+            hipLaunchKernelGGL(pgr_wave_place, dim3(1), dim3(1024), 0, st, cost, (int)waves, B, W, map);
+            a.wave_map = map;
+            blocks = B;
+        }
         size_t lds = (size_t)env->d.nz * sizeof(double2);
         if (env->d.z_simple) {
             HIPCHK(hipFuncSetAttribute((const void*)pgr_fan_kernel<true, true>,
