@@ -1406,8 +1406,25 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
         }
     } else {
         int wpb = g_waves_per_block ? g_waves_per_block : 4;
+        int64_t blocks = (waves + wpb - 1) / wpb;
+        // same single-round placement as above when the fan is 1-2 waves per SIMD (one workgroup
+        // per CU then, although nothing but the grid size keeps the hardware from co-locating two)
+        if (g_waves_per_block == 0 && g_place && waves > 4 * (int64_t)env->num_cus &&
+            waves <= 8 * (int64_t)env->num_cus && env->num_cus * 8 <= 2048) {
+            int B = env->num_cus, W = (int)((waves + B - 1) / B);
+            if (!env->place_buf)
+                HIPCHK(hipMalloc(&env->place_buf, (size_t)pgr_env::kPlaceRing * 2048 * 8));
+            char* slot = (char*)env->place_buf + (size_t)(env->place_next++ % pgr_env::kPlaceRing) * 2048 * 8;
+            float* cost = (float*)slot;
+            int* map = (int*)(slot + 2048 * 4);
+            HIPCHK(hipMemsetAsync(map, 0xFF, (size_t)B * W * sizeof(int), st));
+            hipLaunchKernelGGL(pgr_wave_cost, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, y0, N, (int)waves, cost);
+            hipLaunchKernelGGL(pgr_wave_place, dim3(1), dim3(1024), 0, st, cost, (int)waves, B, W, map);
+            a.wave_map = map;
+            blocks = B;
+            wpb = W;
+        }
         int threads = wpb * 64;
-        int64_t blocks = (N + threads - 1) / threads;
         if (env->d.z_simple)
             hipLaunchKernelGGL((pgr_fan_kernel<false, true>), dim3((unsigned)blocks), dim3(threads), 0, st, env->d_dev, a);
         else

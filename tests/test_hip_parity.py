@@ -263,8 +263,11 @@ def test_full_size_config1_properties(lib):
     y0 = y0_for(oracle, arrs, 1000.0, 0.0, -theta)
     env = lib.EnvHandle(*arrs)
     a = env.shoot_fan(y0, 0.0, 1000e3, 101)
+    lib.set_placement(0)  # cost-aware wave placement off: same rays, same bits, different SIMDs
     b = env.shoot_fan(y0, 0.0, 1000e3, 101)
+    lib.set_placement(1)
     assert np.array_equal(a["end"], b["end"], equal_nan=True) and np.array_equal(a["n_steps"], b["n_steps"])
+    assert np.array_equal(a["z"], b["z"], equal_nan=True) and np.array_equal(a["status"], b["status"])
     ok = a["status"] == 0
     assert ok.mean() > 0.999
     sub = np.arange(0, 100_000, 500)
