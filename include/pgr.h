@@ -108,8 +108,10 @@ int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, double sourc
  * step attempts. */
 int pgr_set_waves_per_block(int waves);
 int pgr_set_park(int lanes, int trips);
-/* Cost-aware wave placement for fans of 1-2 waves per SIMD (default on; 0 = strided deal). */
-int pgr_set_placement(int on);
+/* Cost-aware wave scheduling for fans of 1-2 waves per SIMD: 2 (default) = the costliest
+ * waves get a SIMD to themselves / are paired with the cheapest, plus issue priorities by cost
+ * quartile; 1 = priorities only on the strided deal; 0 = strided deal. */
+int pgr_set_placement(int mode);
 
 /* Unit-level device entry points (for parity tests of a1-a8, REF/integration_processes.py):
  * evaluate on the GPU, for M query points (x[k], y[k][3]) given as HOST arrays:

@@ -236,5 +236,5 @@ def set_park(lanes, trips):
     check(load().pgr_set_park(int(lanes), int(trips)))
 
 
-def set_placement(on):
-    load().pgr_set_placement(int(bool(on)))
+def set_placement(mode):
+    check(load().pgr_set_placement(int(mode)))

@@ -568,8 +568,17 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     // waves are dealt to workgroups round-robin (wave w of block b = global wave w*grid + b):
     // neighbouring launch angles cost alike, so a strided deal balances the CUs
     int64_t gwave = (int64_t)(threadIdx.x >> 6) * gridDim.x + blockIdx.x;
-    if (a.wave_map)  // cost-aware placement (pgr_wave_place): slot -> wave, -1 = slot left empty
-        gwave = a.wave_map[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)];
+    if (a.wave_map) {
+        // cost-aware scheduling (pgr_wave_place): slot -> wave (-1 = slot left empty) and the
+        // wave's issue priority in bits 28..29: the costlier wave of a SIMD's pair runs at its own
+        // pace, the cheaper one fills the issue slots it leaves
+        int m = a.wave_map[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)];
+        gwave = (m < 0) ? -1 : (m & 0x0fffffff);
+        int prio = __builtin_amdgcn_readfirstlane((m < 0) ? 0 : ((m >> 28) & 3));
+        if (prio == 3) __builtin_amdgcn_s_setprio(3);
+        else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+        else if (prio == 1) __builtin_amdgcn_s_setprio(1);
+    }
     const int64_t ray = gwave * 64 + (threadIdx.x & 63);
     const bool valid = (gwave >= 0) && (ray < a.N);
     const double SAFETY = 0.9, MIN_FACTOR = 0.2, MAX_FACTOR = 10;
@@ -989,7 +998,8 @@ __global__ void pgr_wave_cost(const double* __restrict__ y0, int64_t N, int n_wa
 }
 
 __global__ void __launch_bounds__(1024)
-pgr_wave_place(const float* __restrict__ cost, int n_waves, int B, int W, int* __restrict__ map)
+pgr_wave_place(const float* __restrict__ cost, int n_waves, int B, int W, int strided,
+               int* __restrict__ map)
 {
     __shared__ float sc[2048];
     for (int i = threadIdx.x; i < n_waves; i += blockDim.x) sc[i] = cost[i];
@@ -1005,7 +1015,10 @@ pgr_wave_place(const float* __restrict__ cost, int n_waves, int B, int W, int* _
         int r = 0;                                    // rank by descending cost (ties: index)
         for (int k = 0; k < n_waves; k++) r += (sc[k] > c) || (sc[k] == c && k < w);
         int block, slot;
-        if (r < n_lone) {
+        if (strided) {            // keep the round-robin deal, only attach priorities
+            block = w % B;
+            slot = w / B;
+        } else if (r < n_lone) {
             block = r % B;
             slot = (W - 4) + r / B;
         } else if (r < n_lone + E) {
@@ -1020,7 +1033,8 @@ pgr_wave_place(const float* __restrict__ cost, int n_waves, int B, int W, int* _
             block = q % B;
             slot = q / B + (first ? 0 : 4);
         }
-        map[block * W + slot] = w;
+        int prio = 3 - min(3, (4 * r) / n_waves);  // cost quartile
+        map[block * W + slot] = w | (prio << 28);
     }
 }
 
@@ -1080,7 +1094,7 @@ __global__ void pgr_math_kernel(const double* a, const double* b, int64_t M, dou
 static thread_local std::string g_err;
 static int g_waves_per_block = 0;
 static int g_park_lanes = 64, g_park_trips = 16;
-static int g_place = 1;  // cost-aware wave placement (pgr_set_placement)
+static int g_place = 2;  // 0 off, 1 issue priorities only, 2 cost-aware placement + priorities
 
 static int fail(const std::string& m)
 {
@@ -1131,9 +1145,10 @@ extern "C" int pgr_set_park(int lanes, int trips)
     return 0;
 }
 
-extern "C" int pgr_set_placement(int on)
+extern "C" int pgr_set_placement(int mode)
 {
-    g_place = on ? 1 : 0;
+    if (mode < 0 || mode > 2) return fail("pgr_set_placement: 0 = off, 1 = priorities only, 2 = placement + priorities");
+    g_place = mode;
     return 0;
 }
 
@@ -1382,7 +1397,8 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
         // by cost (see pgr_wave_place); otherwise the strided deal
         if (g_waves_per_block == 0 && g_place && waves > 4 * (int64_t)env->num_cus &&
             waves <= 8 * (int64_t)env->num_cus && env->num_cus * 8 <= 2048) {
-            int B = env->num_cus, W = wpb;  // W = ceil(waves / CUs) in 5..8
+            int W = wpb;  // W = ceil(waves / CUs) in 5..8
+            int B = (g_place == 1) ? (int)((waves + W - 1) / W) : env->num_cus;
             if (!env->place_buf)
                 HIPCHK(hipMalloc(&env->place_buf, (size_t)pgr_env::kPlaceRing * 2048 * 8));
             char* slot = (char*)env->place_buf + (size_t)(env->place_next++ % pgr_env::kPlaceRing) * 2048 * 8;
@@ -1390,7 +1406,7 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
             int* map = (int*)(slot + 2048 * 4);
             HIPCHK(hipMemsetAsync(map, 0xFF, (size_t)B * W * sizeof(int), st));
             hipLaunchKernelGGL(pgr_wave_cost, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, y0, N, (int)waves, cost);
-            hipLaunchKernelGGL(pgr_wave_place, dim3(1), dim3(1024), 0, st, cost, (int)waves, B, W, map);
+            hipLaunchKernelGGL(pgr_wave_place, dim3(1), dim3(1024), 0, st, cost, (int)waves, B, W, g_place == 1, map);
             a.wave_map = map;
             blocks = B;
         }
@@ -1411,7 +1427,8 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
         // per CU then, although nothing but the grid size keeps the hardware from co-locating two)
         if (g_waves_per_block == 0 && g_place && waves > 4 * (int64_t)env->num_cus &&
             waves <= 8 * (int64_t)env->num_cus && env->num_cus * 8 <= 2048) {
-            int B = env->num_cus, W = (int)((waves + B - 1) / B);
+            int W = (int)((waves + env->num_cus - 1) / env->num_cus);
+            int B = (g_place == 1) ? (int)((waves + W - 1) / W) : env->num_cus;
             if (!env->place_buf)
                 HIPCHK(hipMalloc(&env->place_buf, (size_t)pgr_env::kPlaceRing * 2048 * 8));
             char* slot = (char*)env->place_buf + (size_t)(env->place_next++ % pgr_env::kPlaceRing) * 2048 * 8;
@@ -1419,7 +1436,7 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
             int* map = (int*)(slot + 2048 * 4);
             HIPCHK(hipMemsetAsync(map, 0xFF, (size_t)B * W * sizeof(int), st));
             hipLaunchKernelGGL(pgr_wave_cost, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, y0, N, (int)waves, cost);
-            hipLaunchKernelGGL(pgr_wave_place, dim3(1), dim3(1024), 0, st, cost, (int)waves, B, W, map);
+            hipLaunchKernelGGL(pgr_wave_place, dim3(1), dim3(1024), 0, st, cost, (int)waves, B, W, g_place == 1, map);
             a.wave_map = map;
             blocks = B;
             wpb = W;

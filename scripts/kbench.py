@@ -18,7 +18,7 @@ ap.add_argument("--modes", nargs="*", default=["nosave", "ray", "sample"])
 ap.add_argument("--slope", type=float, default=0.0, help="sofar slope -> range dependent")
 ap.add_argument("--S", type=int, default=1001)
 ap.add_argument("--lib", default=None)
-ap.add_argument("--noplace", action="store_true")
+ap.add_argument("--place", type=int, default=-1)
 ap.add_argument("--park", type=int, nargs="*", default=[64, 16], help="pairs: lanes trips lanes trips ...")
 ap.add_argument("--exact", action="store_true")
 a = ap.parse_args()
@@ -26,8 +26,8 @@ if a.lib:
     _lib.LIB_PATH = os.path.abspath(a.lib)
 arrs = munk_arrays(a.km * 1e3, nr=(101 if a.slope else 100), sofar_slope=a.slope)
 env = _lib.EnvHandle(*arrs)
-if a.noplace:
-    _lib.set_placement(0)
+if a.place >= 0:
+    _lib.set_placement(a.place)
 theta = np.linspace(a.amin, a.amax, a.rays)
 y0 = fan_y0(arrs, 1000.0, 0.0, -theta)
 for mode in a.modes:

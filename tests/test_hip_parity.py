@@ -263,9 +263,13 @@ def test_full_size_config1_properties(lib):
     y0 = y0_for(oracle, arrs, 1000.0, 0.0, -theta)
     env = lib.EnvHandle(*arrs)
     a = env.shoot_fan(y0, 0.0, 1000e3, 101)
-    lib.set_placement(0)  # cost-aware wave placement off: same rays, same bits, different SIMDs
+    lib.set_placement(0)  # cost-aware wave scheduling off: same rays, same bits, different SIMDs
     b = env.shoot_fan(y0, 0.0, 1000e3, 101)
     lib.set_placement(1)
+    b1 = env.shoot_fan(y0[:80000], 0.0, 1000e3, 3)
+    lib.set_placement(2)
+    b2 = env.shoot_fan(y0[:80000], 0.0, 1000e3, 3)
+    assert np.array_equal(b1["end"], b2["end"], equal_nan=True) and np.array_equal(b1["end"], a["end"][:80000], equal_nan=True)
     assert np.array_equal(a["end"], b["end"], equal_nan=True) and np.array_equal(a["n_steps"], b["n_steps"])
     assert np.array_equal(a["z"], b["z"], equal_nan=True) and np.array_equal(a["status"], b["status"])
     ok = a["status"] == 0
