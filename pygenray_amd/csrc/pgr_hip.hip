@@ -997,12 +997,37 @@ __global__ void pgr_wave_cost(const double* __restrict__ y0, int64_t N, int n_wa
     if ((threadIdx.x & 63) == 0) cost[w] = c;
 }
 
+// Ranks the waves by descending cost with a 4096-bin counting sort (order inside a bin is
+// irrelevant for scheduling) and writes slot -> wave.  mode 1: strided deal + priorities;
+// mode 2, single round (n_waves <= B*W): lone / empty-partner / expensive-with-cheap placement;
+// mode 3, several rounds: workgroup b gets the waves of rank b*W .. b*W+W-1, so that every
+// workgroup is homogeneous (it holds its CU and LDS until its LAST wave ends) and workgroups
+// are dispatched longest first.
 __global__ void __launch_bounds__(1024)
-pgr_wave_place(const float* __restrict__ cost, int n_waves, int B, int W, int strided,
+pgr_wave_place(const float* __restrict__ cost, int n_waves, int B, int W, int mode,
                int* __restrict__ map)
 {
-    __shared__ float sc[2048];
-    for (int i = threadIdx.x; i < n_waves; i += blockDim.x) sc[i] = cost[i];
+    constexpr int NB = 4096;
+    __shared__ int bins[NB];      // count, then exclusive prefix from the expensive end
+    __shared__ int cursor[NB];
+    __shared__ float smax[1024];
+    float mx = 0.0f;
+    for (int i = threadIdx.x; i < n_waves; i += blockDim.x) mx = fmaxf(mx, cost[i]);
+    smax[threadIdx.x] = mx;
+    for (int i = threadIdx.x; i < NB; i += blockDim.x) { bins[i] = 0; cursor[i] = 0; }
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + o]);
+        __syncthreads();
+    }
+    const float scale = smax[0] > 0.0f ? (float)(NB - 1) / smax[0] : 0.0f;
+    for (int i = threadIdx.x; i < n_waves; i += blockDim.x)
+        atomicAdd(&bins[min(NB - 1, (int)(cost[i] * scale))], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {       // exclusive prefix, most expensive bin first
+        int acc = 0;
+        for (int k = NB - 1; k >= 0; k--) { int c = bins[k]; bins[k] = acc; acc += c; }
+    }
     __syncthreads();
     const int lone_per_block = 8 - W;                 // waves W-4 .. 3
     const int n_lone = B * lone_per_block;
@@ -1011,30 +1036,27 @@ pgr_wave_place(const float* __restrict__ cost, int n_waves, int B, int W, int st
     int E = spare < pairs ? spare : pairs;            // pair slots run with an empty partner
     const int P = pairs - E;                          // fully used pairs
     for (int w = threadIdx.x; w < n_waves; w += blockDim.x) {
-        float c = sc[w];
-        int r = 0;                                    // rank by descending cost (ties: index)
-        for (int k = 0; k < n_waves; k++) r += (sc[k] > c) || (sc[k] == c && k < w);
-        int block, slot;
-        if (strided) {            // keep the round-robin deal, only attach priorities
-            block = w % B;
-            slot = w / B;
+        int bin = min(NB - 1, (int)(cost[w] * scale));
+        int r = bins[bin] + atomicAdd(&cursor[bin], 1);   // rank by descending cost
+        int idx;
+        if (mode == 1) {                              // keep the round-robin deal
+            idx = (w % B) * W + w / B;
+        } else if (mode == 3) {                       // cost-sorted, homogeneous workgroups
+            idx = r;
         } else if (r < n_lone) {
-            block = r % B;
-            slot = (W - 4) + r / B;
+            idx = (r % B) * W + (W - 4) + r / B;
         } else if (r < n_lone + E) {
             int q = r - n_lone;
-            block = q % B;
-            slot = q / B;                             // partner slot + 4 stays empty
+            idx = (q % B) * W + q / B;                // partner slot + 4 stays empty
         } else {
             int p = r - n_lone - E;                   // 0 .. 2P-1, descending cost
             int first = p < P;
             int pi = first ? p : (2 * P - 1 - p);     // expensive half meets cheap half
             int q = E + pi;
-            block = q % B;
-            slot = q / B + (first ? 0 : 4);
+            idx = (q % B) * W + q / B + (first ? 0 : 4);
         }
-        int prio = 3 - min(3, (4 * r) / n_waves);  // cost quartile
-        map[block * W + slot] = w | (prio << 28);
+        int prio = 3 - min(3, (int)((4LL * r) / n_waves));  // cost quartile
+        map[idx] = w | (prio << 28);
     }
 }
 
@@ -1119,7 +1141,8 @@ struct pgr_env {
     std::mutex ws_mutex;
     // ring of small buffers for the per-launch wave placement (cost[2048] + map[2048])
     static constexpr int kPlaceRing = 8;
-    void* place_buf = nullptr;
+    void* place_buf = nullptr;     // owned through `allocs`
+    size_t place_slot_bytes = 0;
     int place_next = 0;
     int range_indep = 0;
     int lds_path = 0;
@@ -1231,7 +1254,6 @@ extern "C" void pgr_env_destroy(pgr_env* env)
     (void)hipSetDevice(env->device);
     for (void* p : env->allocs) (void)hipFree(p);
     if (env->ws) (void)hipFree(env->ws);
-    if (env->place_buf) (void)hipFree(env->place_buf);
     delete env;
 }
 
@@ -1344,6 +1366,46 @@ extern "C" int pgr_env_query(const pgr_env* env, int what)
     }
 }
 
+// Builds the slot -> wave map for this launch on `st` (see pgr_wave_place); returns the map and
+// the grid size through the references, or leaves map null when scheduling is off / not useful.
+static int schedule_waves(pgr_env* env, const double* y0, int64_t N, int64_t waves, int W, hipStream_t st,
+                          const int*& map_out, int64_t& blocks)
+{
+    map_out = nullptr;
+    if (g_place == 0 || g_waves_per_block != 0 || W < 5 || waves > (1 << 27)) return 0;
+    const int64_t cus = env->num_cus;
+    int mode, B;
+    if (waves <= 8 * cus && W <= 8 && waves > 4 * cus) {  // single round, 1-2 waves per SIMD
+        mode = g_place;                                     // 1 or 2
+        B = (mode == 1) ? (int)((waves + W - 1) / W) : (int)cus;
+    } else if (waves > 8 * cus) {                           // several rounds
+        mode = 3;
+        B = (int)((waves + W - 1) / W);
+    } else {
+        return 0;
+    }
+    size_t n_slots = (size_t)B * W;
+    size_t need = ((size_t)waves * 4 + n_slots * 4 + 511) & ~(size_t)255;
+    if (need > env->place_slot_bytes) {  // grow-only ring (previous launches may still read theirs:
+        // the old buffer is kept until the env dies)
+        size_t sz = need > 65536 ? need : 65536;
+        void* nb = nullptr;
+        HIPCHK(hipMalloc(&nb, sz * pgr_env::kPlaceRing));
+        env->allocs.push_back(nb);
+        env->place_buf = nb;
+        env->place_slot_bytes = sz;
+    }
+    char* slot = (char*)env->place_buf + (size_t)(env->place_next++ % pgr_env::kPlaceRing) * env->place_slot_bytes;
+    float* cost = (float*)slot;
+    int* map = (int*)(slot + (((size_t)waves * 4 + 255) & ~(size_t)255));
+    HIPCHK(hipMemsetAsync(map, 0xFF, n_slots * sizeof(int), st));
+    hipLaunchKernelGGL(pgr_wave_cost, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, y0, N, (int)waves, cost);
+    hipLaunchKernelGGL(pgr_wave_place, dim3(1), dim3(1024), 0, st, cost, (int)waves, B, W, mode, map);
+    map_out = map;
+    blocks = B;
+    return 0;
+}
+
 extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, double source_range,
                                     double receiver_range, const double* r_save, int32_t S,
                                     double rtol, double atol, uint32_t flags, int64_t max_steps,
@@ -1393,23 +1455,8 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
         }
         int threads = wpb * 64;
         int64_t blocks = (N + threads - 1) / threads;
-        // 1-2 waves per SIMD in a single round: widen the grid to every CU and place the waves
-        // by cost (see pgr_wave_place); otherwise the strided deal
-        if (g_waves_per_block == 0 && g_place && waves > 4 * (int64_t)env->num_cus &&
-            waves <= 8 * (int64_t)env->num_cus && env->num_cus * 8 <= 2048) {
-            int W = wpb;  // W = ceil(waves / CUs) in 5..8
-            int B = (g_place == 1) ? (int)((waves + W - 1) / W) : env->num_cus;
-            if (!env->place_buf)
-                HIPCHK(hipMalloc(&env->place_buf, (size_t)pgr_env::kPlaceRing * 2048 * 8));
-            char* slot = (char*)env->place_buf + (size_t)(env->place_next++ % pgr_env::kPlaceRing) * 2048 * 8;
-            float* cost = (float*)slot;
-            int* map = (int*)(slot + 2048 * 4);
-            HIPCHK(hipMemsetAsync(map, 0xFF, (size_t)B * W * sizeof(int), st));
-            hipLaunchKernelGGL(pgr_wave_cost, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, y0, N, (int)waves, cost);
-            hipLaunchKernelGGL(pgr_wave_place, dim3(1), dim3(1024), 0, st, cost, (int)waves, B, W, g_place == 1, map);
-            a.wave_map = map;
-            blocks = B;
-        }
+        // cost-aware scheduling of the waves (placement, priorities, homogeneous workgroups)
+        if (schedule_waves(env, y0, N, waves, wpb, st, a.wave_map, blocks)) return -1;
         size_t lds = (size_t)env->d.nz * sizeof(double2);
         if (env->d.z_simple) {
             HIPCHK(hipFuncSetAttribute((const void*)pgr_fan_kernel<true, true>,
@@ -1423,23 +1470,13 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
     } else {
         int wpb = g_waves_per_block ? g_waves_per_block : 4;
         int64_t blocks = (waves + wpb - 1) / wpb;
-        // same single-round placement as above when the fan is 1-2 waves per SIMD (one workgroup
-        // per CU then, although nothing but the grid size keeps the hardware from co-locating two)
-        if (g_waves_per_block == 0 && g_place && waves > 4 * (int64_t)env->num_cus &&
-            waves <= 8 * (int64_t)env->num_cus && env->num_cus * 8 <= 2048) {
-            int W = (int)((waves + env->num_cus - 1) / env->num_cus);
-            int B = (g_place == 1) ? (int)((waves + W - 1) / W) : env->num_cus;
-            if (!env->place_buf)
-                HIPCHK(hipMalloc(&env->place_buf, (size_t)pgr_env::kPlaceRing * 2048 * 8));
-            char* slot = (char*)env->place_buf + (size_t)(env->place_next++ % pgr_env::kPlaceRing) * 2048 * 8;
-            float* cost = (float*)slot;
-            int* map = (int*)(slot + 2048 * 4);
-            HIPCHK(hipMemsetAsync(map, 0xFF, (size_t)B * W * sizeof(int), st));
-            hipLaunchKernelGGL(pgr_wave_cost, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, y0, N, (int)waves, cost);
-            hipLaunchKernelGGL(pgr_wave_place, dim3(1), dim3(1024), 0, st, cost, (int)waves, B, W, g_place == 1, map);
-            a.wave_map = map;
-            blocks = B;
-            wpb = W;
+        // the same scheduling; a fan too small for it keeps 4-wave workgroups
+        if (waves > 4 * (int64_t)env->num_cus) {
+            int W = waves <= 8 * (int64_t)env->num_cus ? (int)((waves + env->num_cus - 1) / env->num_cus) : 8;
+            const int* m = nullptr;
+            int64_t nb2 = blocks;
+            if (schedule_waves(env, y0, N, waves, W, st, m, nb2)) return -1;
+            if (m) { a.wave_map = m; blocks = nb2; wpb = W; }
         }
         int threads = wpb * 64;
         if (env->d.z_simple)
