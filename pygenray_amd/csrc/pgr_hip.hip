@@ -1144,6 +1144,7 @@ struct pgr_env {
     void* place_buf = nullptr;     // owned through `allocs`
     size_t place_slot_bytes = 0;
     int place_next = 0;
+    std::mutex place_mutex;
     int range_indep = 0;
     int lds_path = 0;
     std::vector<void*> allocs;
@@ -1384,6 +1385,7 @@ static int schedule_waves(pgr_env* env, const double* y0, int64_t N, int64_t wav
     } else {
         return 0;
     }
+    std::lock_guard<std::mutex> lock(env->place_mutex);  // host threads may share an env
     size_t n_slots = (size_t)B * W;
     size_t need = ((size_t)waves * 4 + n_slots * 4 + 511) & ~(size_t)255;
     if (need > env->place_slot_bytes) {  // grow-only ring (previous launches may still read theirs:
