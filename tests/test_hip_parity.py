@@ -387,3 +387,32 @@ def test_sharded_hip_compute_single_rank(lib):
     assert np.array_equal(nb.cpu().numpy(), ref["n_bott"]) and np.array_equal(st.cpu().numpy(), ref["status"])
     h = arrival_time_histogram(end[:, 0], st, 32, 66.0, 68.0)
     assert int(h.sum().item()) == int(((ref["status"] == 0) & (ref["end"][:, 0] >= 66) & (ref["end"][:, 0] <= 68)).sum())
+
+
+def test_wave_scheduler_is_a_pure_permutation(lib):
+    """Cost-aware scheduling (placement, priorities, cost-sorted workgroups) only decides where
+    and when a wave runs: for fan sizes around every regime boundary the results are bit-identical
+    to the plain strided deal and every ray is integrated exactly once."""
+    arrs = munk_arrays(60e3, nr=12)
+    env = lib.EnvHandle(*arrs)
+    cus = 256
+    sizes = [4 * cus * 64 + 1, 5 * cus * 64, 7 * cus * 64 - 63, 8 * cus * 64, 8 * cus * 64 + 1, 150_000]
+    for n in sizes:
+        y0 = y0_for(oracle, arrs, 900.0, 0.0, np.linspace(-19, 19, n))
+        lib.set_placement(0)
+        ref = env.shoot_fan(y0, 0.0, 60e3, 1, save=False)
+        for mode in (1, 2):
+            lib.set_placement(mode)
+            got = env.shoot_fan(y0, 0.0, 60e3, 1, save=False)
+            assert np.array_equal(got["end"], ref["end"], equal_nan=True), (n, mode)
+            assert np.array_equal(got["n_steps"], ref["n_steps"]) and np.array_equal(got["status"], ref["status"])
+    lib.set_placement(2)
+    # range-dependent (no LDS table) path as well
+    arrs2 = munk_arrays(60e3, nr=13, sofar_slope=1e-3)
+    env2 = lib.EnvHandle(*arrs2)
+    y0 = y0_for(oracle, arrs2, 900.0, 0.0, np.linspace(-19, 19, 90_000))
+    lib.set_placement(0)
+    ref = env2.shoot_fan(y0, 0.0, 60e3, 1, save=False)
+    lib.set_placement(2)
+    got = env2.shoot_fan(y0, 0.0, 60e3, 1, save=False)
+    assert np.array_equal(got["end"], ref["end"], equal_nan=True) and np.array_equal(got["status"], ref["status"])
