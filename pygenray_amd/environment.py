@@ -160,7 +160,9 @@ def _unpack_envi(environment, flatearth=True):
     cin, cpin (= d c / d depth by np.gradient, as xarray's differentiate), rin, zin, depths,
     depth_ranges, bottom_angles."""
     cache = getattr(environment, "_cache", None)
-    key = ("arrays", bool(flatearth))
+    src = (getattr(environment, "sound_speed_fe", None) if flatearth else environment.sound_speed,
+           getattr(environment, "bathymetry_fe", None) if flatearth else environment.bathymetry)
+    key = ("arrays", bool(flatearth), id(src[0]), id(src[1]))
     if cache is not None and key in cache:
         return cache[key]
     if flatearth:

@@ -28,7 +28,11 @@ def _device_env(environment, flatearth, backwards, device=0):
     cache = getattr(environment, "_cache", None)
     if cache is None:
         cache = environment._cache = {}
-    key = ("dev", bool(flatearth), bool(backwards), int(device))
+    # keyed on the identity of the tables too: replacing env.sound_speed / env.bathymetry (or
+    # re-running the flat-earth transform) uploads afresh; in-place edits of .values do not
+    src = (getattr(environment, "sound_speed_fe", None) if flatearth else environment.sound_speed,
+           getattr(environment, "bathymetry_fe", None) if flatearth else environment.bathymetry)
+    key = ("dev", bool(flatearth), bool(backwards), int(device), id(src[0]), id(src[1]))
     if key not in cache:
         cin, cpin, rin, zin, depths, depth_ranges, bottom_angles = _unpack_envi(
             environment, flatearth=flatearth)

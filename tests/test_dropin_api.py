@@ -189,3 +189,37 @@ def test_find_eigenrays_matches_reference():
     assert np.all(np.abs(er.zs[0][:, -1] + 1000.0) < 1.0)
     assert er.rs[0].shape == (4, 21) and er.received_angles[0].shape == (4,)
     assert er.failed_eray_theta_brackets[0] == []
+
+
+def test_find_eigenrays_several_receiver_depths_and_structure():
+    z = np.arange(0, 6000, 1.0)
+    r = np.linspace(0, 100e3, 100)
+    env = _env(np.tile(munk_ssp(z), (100, 1)), z, r, np.full(100, 5000.0))
+    fan = shoot_rays(1000.0, 0.0, np.linspace(-14, 14, 141), 100e3, 31, env, debug=False, flatearth=False)
+    rds = [500.0, 1000.0, 3000.0]
+    er = pr.find_eigenrays(fan, rds, 1000.0, 0.0, 100e3, 31, env, ztol=1, max_iter=20, debug=False,
+                           flatearth=False)
+    for k, rd in enumerate(rds):
+        n_br = er.num_eigenrays[rd]
+        # brackets = sign changes of (z_end + receiver_depth) between neighbouring fan rays
+        assert n_br == int(np.count_nonzero(np.diff(np.sign(fan.zs[:, -1] + rd))))
+        assert er.num_eigenrays_found[k] + len(er.failed_eray_theta_brackets[k]) == n_br
+        assert er.zs[k].shape == (er.num_eigenrays_found[k], 31) == er.ts[k].shape
+        assert np.all(np.abs(er.zs[k][:, -1] + rd) < 1.0)            # within ztol of the receiver
+        assert np.all(np.diff(er.launch_angles[k]) > 0)              # bracket order = launch-angle order
+        assert er.received_angles[k].shape == er.launch_angles[k].shape == er.ray_id[k].shape
+        # every eigenray's launch angle lies inside a fan bracket
+        idx = np.searchsorted(fan.thetas, er.launch_angles[k])
+        assert np.all((idx > 0) & (idx < len(fan.thetas)))
+    assert er.num_eigenrays_found[1] >= 3
+
+
+def test_environment_cache_follows_replaced_tables():
+    z = np.arange(0, 6000, 2.0)
+    r = np.linspace(0, 50e3, 20)
+    env = _env(np.tile(munk_ssp(z), (20, 1)), z, r, np.full(20, 5000.0))
+    a = shoot_ray(1000.0, 0.0, 4.0, 50e3, 11, env, debug=False, flatearth=False)
+    env.sound_speed = DataArray(np.tile(munk_ssp(z, sofar_depth=1000.0), (20, 1)), dims=["range", "depth"],
+                                coords={"range": r, "depth": z})
+    b = shoot_ray(1000.0, 0.0, 4.0, 50e3, 11, env, debug=False, flatearth=False)
+    assert abs(a.z[-1] - b.z[-1]) > 1.0
