@@ -55,6 +55,11 @@ extern "C" {
 #define PGR_DEBUG_TRIPS 16u       /* diagnostics: n_rej[] receives, per wave, the number of main-loop
                                       trips (lane 0) and of service phases (other lanes) instead */
 
+#define PGR_EXACT_SAMPLES 32u      /* evaluate the saved samples with SciPy's own summation order
+                                      (Q = K.T @ P, then h * (Q @ p) + y_old, SCIPY/rk.py:552-574)
+                                      instead of the default stage-major FMA form of the same quartic
+                                      (a few ulp apart; samples never feed back into the integration) */
+
 typedef struct pgr_env pgr_env; /* opaque: environment tables resident in HBM */
 
 /* Number of visible HIP devices (<0 on error). */

@@ -25,6 +25,7 @@ else:                               # default: reference arithmetic, cheaper cor
 PGR_TERMINATE_BACKWARDS = 1
 PGR_SAMPLE_MAJOR = 2
 PGR_EXACT_BISECTION = 4
+PGR_EXACT_SAMPLES = 32
 PGR_SAVE_LINSPACE = 8
 
 RAY_STATUS = {0: "ok", 1: "vertical", 2: "bbox", 3: "backward", 4: "step_too_small",
@@ -173,13 +174,14 @@ class EnvHandle:
     # ---- host-pointer entry (NumPy in / NumPy out) ----
     def shoot_fan(self, y0, source_range, receiver_range, num_range_save, rtol=1e-9, atol=1e-6,
                   terminate_backwards=True, max_steps=1_000_000, save=True, sample_major=False,
-                  exact_bisection=False):
+                  exact_bisection=False, exact_samples=False):
         L = load()
         y0 = _c(y0).reshape(-1, 3)
         N, S = len(y0), int(num_range_save)
         r = np.linspace(source_range, receiver_range, S)
         flags = (PGR_TERMINATE_BACKWARDS if terminate_backwards else 0) | \
-            (PGR_SAMPLE_MAJOR if sample_major else 0) | (PGR_EXACT_BISECTION if exact_bisection else 0)
+            (PGR_SAMPLE_MAJOR if sample_major else 0) | (PGR_EXACT_BISECTION if exact_bisection else 0) | \
+            (PGR_EXACT_SAMPLES if exact_samples else 0)
         if save:
             shape = (S, N) if sample_major else (N, S)
             T = np.empty(shape); Z = np.empty(shape); P = np.empty(shape)

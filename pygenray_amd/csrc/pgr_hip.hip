@@ -509,6 +509,25 @@ struct Dense {
 #define P72 (-110615467.0 / 29380423)
 #define P73 (69997945.0 / 29380423)
 
+// Q = K.T @ P of the step just taken (SCIPY/rk.py:552-556); column 0 of P is e_1, so
+// K.T @ P[:, 0] = K1 exactly (the other terms are +0.0)
+#define PGR_FORM_Q()                                                                    \
+    do {                                                                                \
+        D.h = h;                                                                        \
+        D.q[0][0] = f0;                                                                 \
+        D.q[0][1] = PQ(f0, k30, k40, k50, k60, k70, 1);                                 \
+        D.q[0][2] = PQ(f0, k30, k40, k50, k60, k70, 2);                                 \
+        D.q[0][3] = PQ(f0, k30, k40, k50, k60, k70, 3);                                 \
+        D.q[1][0] = f1;                                                                 \
+        D.q[1][1] = PQ(f1, k31, k41, k51, k61, k71, 1);                                 \
+        D.q[1][2] = PQ(f1, k31, k41, k51, k61, k71, 2);                                 \
+        D.q[1][3] = PQ(f1, k31, k41, k51, k61, k71, 3);                                 \
+        D.q[2][0] = f2;                                                                 \
+        D.q[2][1] = PQ(f2, k32, k42, k52, k62, k72, 1);                                 \
+        D.q[2][2] = PQ(f2, k32, k42, k52, k62, k72, 2);                                 \
+        D.q[2][3] = PQ(f2, k32, k42, k52, k62, k72, 3);                                 \
+    } while (0)
+
 // the save grid np.linspace(x0, x1, S): either recomputed per index exactly as NumPy does
 // (arange(S) * step + start, last point forced to x1 -- verified bitwise on the host) or loaded
 struct SaveGrid {
@@ -585,6 +604,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     const double rtol = a.rtol, atol = a.atol, t_bound = a.x1;
     const int S = a.S;
     const bool save = (a.T != nullptr);
+    const bool exact_samples = (a.flags & PGR_EXACT_SAMPLES) != 0;
     SaveGrid G;
     G.r = a.r_save; G.x0 = a.x0; G.x1 = a.x1; G.step = a.save_step; G.inv_step = a.inv_dsave;
     G.S = S; G.formula = a.save_formula;
@@ -602,10 +622,10 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     int nb = 0, ns = 0, n_steps = 0, n_rej = 0;
     int jnext = 0;
     double rnext = 0;
-    // dense output of the step a parked lane is holding (t_old = t, y_old = y are still live)
-    Dense D;
-    D.h = 1;
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) D.q[i][j] = 0;
+    // A parked lane keeps the dense output of the step it is holding in LDS, 13 doubles per lane
+    // laid out [13][blockDim.x] behind the table (t_old = t, y_old = y stay live in registers):
+    // written once per boundary hit, read once per service, and 26 VGPRs less loop-carried state.
+    double* const pk_lds = (double*)(lds_tab + (LDS_TAB ? env.nz : 0)) + threadIdx.x;
     double pk_tnew = 0;
     unsigned pk_active = 0;
     int waited = 0;
@@ -630,6 +650,12 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                 if (pend && parked) {
                     parked = false;
                     const unsigned active = pk_active;
+                    Dense D;
+                    D.h = pk_lds[0];
+#pragma unroll
+                    for (int i = 0; i < 3; i++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) D.q[i][j] = pk_lds[(1 + 4 * i + j) * blockDim.x];
                     const double t_new = pk_tnew, h = D.h;
                     int ev = -1;
                     double best = 0;
@@ -897,39 +923,67 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                 unsigned active = (up & 3u) | ((up | down) & 12u);
                 g = g_new;
                 bool want_samples = save && (jnext < S - 1) && (rnext <= t_new);
-                if (active || want_samples) {
-                    D.h = h;
-                    // column 0 of P is e_1: K.T @ P[:, 0] = K1 exactly (the other terms are +0.0)
-                    D.q[0][0] = f0;
-                    D.q[0][1] = PQ(f0, k30, k40, k50, k60, k70, 1);
-                    D.q[0][2] = PQ(f0, k30, k40, k50, k60, k70, 2);
-                    D.q[0][3] = PQ(f0, k30, k40, k50, k60, k70, 3);
-                    D.q[1][0] = f1;
-                    D.q[1][1] = PQ(f1, k31, k41, k51, k61, k71, 1);
-                    D.q[1][2] = PQ(f1, k31, k41, k51, k61, k71, 2);
-                    D.q[1][3] = PQ(f1, k31, k41, k51, k61, k71, 3);
-                    D.q[2][0] = f2;
-                    D.q[2][1] = PQ(f2, k32, k42, k52, k62, k72, 1);
-                    D.q[2][2] = PQ(f2, k32, k42, k52, k62, k72, 2);
-                    D.q[2][3] = PQ(f2, k32, k42, k52, k62, k72, 3);
+                // samples behind the step (rnext < t: the extrapolated ones a segment's first step
+                // owns, Q5, |xi| up to 1e5) amplify rounding by xi^4 and keep SciPy's order
+                const bool scipy_order = exact_samples || (rnext < t);
+                Dense D;
+                if (active || (want_samples && scipy_order)) {
+                    PGR_FORM_Q();
                 }
                 if (active) {
                     // park: the step is located, truncated and bounced in the next service phase
                     parked = true;
                     pk_active = active;
                     pk_tnew = t_new;
+                    pk_lds[0] = D.h;
+#pragma unroll
+                    for (int i = 0; i < 3; i++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) pk_lds[(1 + 4 * i + j) * blockDim.x] = D.q[i][j];
                 } else {
                     // ---- _interpolate_ray, streamed (REF/launch_rays.py:763-772, Q5): samples of the
                     // segment slice [idx1, idx2) that this step's quartic owns ----
                     if (want_samples) {
-                        while (jnext < S - 1 && rnext <= t_new) {
-                            double o0, o1, o2;
-                            D.eval(t, y0, y1, y2, rnext, o0, o1, o2);
-                            Tp[(int64_t)jnext * a.stride_smp] = o0;
-                            Zp[(int64_t)jnext * a.stride_smp] = o1;
-                            Pp[(int64_t)jnext * a.stride_smp] = o2;
-                            jnext++;
-                            rnext = G.at(jnext);
+                        if (scipy_order) {
+                            while (jnext < S - 1 && rnext <= t_new) {
+                                double o0, o1, o2;
+                                D.eval(t, y0, y1, y2, rnext, o0, o1, o2);
+                                Tp[(int64_t)jnext * a.stride_smp] = o0;
+                                Zp[(int64_t)jnext * a.stride_smp] = o1;
+                                Pp[(int64_t)jnext * a.stride_smp] = o2;
+                                jnext++;
+                                rnext = G.at(jnext);
+                            }
+                        } else {
+                            // The same quartic summed stage-major, y_old + h * sum_j K_j b_j(xi) with
+                            // b_j(xi) = sum_k P[j][k] xi^(k+1), in FMAs: no Q = K.T @ P to form (a third
+                            // of the work) and a few ulp from SciPy's summation order.  Output samples
+                            // never feed back into the integration, so this cannot move a ray.
+                            const double inv_h = frcp(h);
+#define PGR_KSUM(k1, k3, k4, k5, k6, k7)                                                          \
+    __builtin_fma(k1, b1, __builtin_fma(k3, b3, __builtin_fma(k4, b4, __builtin_fma(k5, b5,      \
+                  __builtin_fma(k6, b6, (k7) * b7)))))
+#define PGR_SAMPLE_LOOP(NEXT)                                                                     \
+    while (jnext < S - 1 && rnext <= t_new) {                                                     \
+        const double xi = (rnext - t) * inv_h, x2 = xi * xi;                                      \
+        const double b1 = xi * __builtin_fma(xi, __builtin_fma(xi, __builtin_fma(xi, P13, P12), P11), P10); \
+        const double b3 = x2 * __builtin_fma(xi, __builtin_fma(xi, P33, P32), P31);               \
+        const double b4 = x2 * __builtin_fma(xi, __builtin_fma(xi, P43, P42), P41);               \
+        const double b5 = x2 * __builtin_fma(xi, __builtin_fma(xi, P53, P52), P51);               \
+        const double b6 = x2 * __builtin_fma(xi, __builtin_fma(xi, P63, P62), P61);               \
+        const double b7 = x2 * __builtin_fma(xi, __builtin_fma(xi, P73, P72), P71);               \
+        Tp[(int64_t)jnext * a.stride_smp] = __builtin_fma(h, PGR_KSUM(f0, k30, k40, k50, k60, k70), y0); \
+        Zp[(int64_t)jnext * a.stride_smp] = __builtin_fma(h, PGR_KSUM(f1, k31, k41, k51, k61, k71), y1); \
+        Pp[(int64_t)jnext * a.stride_smp] = __builtin_fma(h, PGR_KSUM(f2, k32, k42, k52, k62, k72), y2); \
+        jnext++;                                                                                  \
+        rnext = NEXT;                                                                             \
+    }
+                            // two copies so that the linspace one holds no load: a load in the loop
+                            // makes every iteration wait (vmcnt) for the stores of the one before
+                            if (G.formula) { PGR_SAMPLE_LOOP(((jnext >= S - 1) ? G.x1 : grid_at(G.x0, G.step, jnext))) }
+                            else { PGR_SAMPLE_LOOP(G.r[jnext]) }
+#undef PGR_SAMPLE_LOOP
+#undef PGR_KSUM
                         }
                     }
                     t = t_new; y0 = n0; y1 = n1; y2 = n2;
@@ -1115,6 +1169,7 @@ __global__ void pgr_math_kernel(const double* a, const double* b, int64_t M, dou
 // ====================================================================================
 static thread_local std::string g_err;
 static int g_waves_per_block = 0;
+static const size_t PARK_BYTES = 13 * sizeof(double);  // h + Q[3][4] of a parked lane (LDS)
 static int g_park_lanes = 64, g_park_trips = 16;
 static int g_place = 2;  // 0 off, 1 issue priorities only, 2 cost-aware placement + priorities
 
@@ -1306,7 +1361,8 @@ extern "C" int pgr_env_create(pgr_env** out, int device, const double* cin, cons
     std::vector<double2> tab(rows * (size_t)nz);
     for (size_t i = 0; i < rows; i++)
         for (int64_t j = 0; j < nz; j++) tab[i * nz + j] = make_double2(cin[i * nz + j], cpin[i * nz + j]);
-    e->lds_path = indep && ((size_t)nz * sizeof(double2) <= e->max_lds);
+    // the LDS table needs room beside it for at least 4 waves' parked dense outputs
+    e->lds_path = indep && ((size_t)nz * sizeof(double2) + PARK_BYTES * 256 <= e->max_lds);
     std::vector<double> pp;
     if (!build_notaknot(depth_ranges, bottom_angles, nb, pp)) {
         delete e;
@@ -1455,11 +1511,15 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
             if (wpb < 1) wpb = 1;
             if (wpb > 8) wpb = 8;
         }
+        // the table shares the LDS with the parked lanes' dense outputs (PARK_BYTES per lane)
+        const size_t tab_bytes = (size_t)env->d.nz * sizeof(double2);
+        const int wpb_fit = (int)((env->max_lds - tab_bytes) / (PARK_BYTES * 64));
+        if (wpb > wpb_fit) wpb = wpb_fit;
         int threads = wpb * 64;
         int64_t blocks = (N + threads - 1) / threads;
         // cost-aware scheduling of the waves (placement, priorities, homogeneous workgroups)
         if (schedule_waves(env, y0, N, waves, wpb, st, a.wave_map, blocks)) return -1;
-        size_t lds = (size_t)env->d.nz * sizeof(double2);
+        size_t lds = tab_bytes + PARK_BYTES * (size_t)threads;
         if (env->d.z_simple) {
             HIPCHK(hipFuncSetAttribute((const void*)pgr_fan_kernel<true, true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1481,10 +1541,11 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
             if (m) { a.wave_map = m; blocks = nb2; wpb = W; }
         }
         int threads = wpb * 64;
+        size_t lds = PARK_BYTES * (size_t)threads;
         if (env->d.z_simple)
-            hipLaunchKernelGGL((pgr_fan_kernel<false, true>), dim3((unsigned)blocks), dim3(threads), 0, st, env->d_dev, a);
+            hipLaunchKernelGGL((pgr_fan_kernel<false, true>), dim3((unsigned)blocks), dim3(threads), lds, st, env->d_dev, a);
         else
-            hipLaunchKernelGGL((pgr_fan_kernel<false, false>), dim3((unsigned)blocks), dim3(threads), 0, st, env->d_dev, a);
+            hipLaunchKernelGGL((pgr_fan_kernel<false, false>), dim3((unsigned)blocks), dim3(threads), lds, st, env->d_dev, a);
     }
     HIPCHK(hipGetLastError());
     return 0;

@@ -17,7 +17,7 @@ class DeviceFan:
 
     def __init__(self, env_handle, y0, source_range, receiver_range, num_range_save, rtol=1e-9,
                  atol=1e-6, terminate_backwards=True, save=True, sample_major=False,
-                 max_steps=1_000_000, exact_bisection=False):
+                 max_steps=1_000_000, exact_bisection=False, exact_samples=False):
         self.env = env_handle
         dev = torch.device("cuda", env_handle.device)
         self.dev = dev
@@ -27,7 +27,8 @@ class DeviceFan:
         self.rtol, self.atol, self.max_steps = float(rtol), float(atol), int(max_steps)
         self.flags = (_lib.PGR_TERMINATE_BACKWARDS if terminate_backwards else 0) | \
             (_lib.PGR_SAMPLE_MAJOR if sample_major else 0) | _lib.PGR_SAVE_LINSPACE | \
-            (_lib.PGR_EXACT_BISECTION if exact_bisection else 0)
+            (_lib.PGR_EXACT_BISECTION if exact_bisection else 0) | \
+            (_lib.PGR_EXACT_SAMPLES if exact_samples else 0)
         self.save, self.sample_major = save, sample_major
         f64 = dict(dtype=torch.float64, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)

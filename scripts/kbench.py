@@ -21,6 +21,7 @@ ap.add_argument("--lib", default=None)
 ap.add_argument("--place", type=int, default=-1)
 ap.add_argument("--park", type=int, nargs="*", default=[64, 16], help="pairs: lanes trips lanes trips ...")
 ap.add_argument("--exact", action="store_true")
+ap.add_argument("--exact-samples", action="store_true")
 a = ap.parse_args()
 if a.lib:
     _lib.LIB_PATH = os.path.abspath(a.lib)
@@ -31,7 +32,7 @@ if a.place >= 0:
 theta = np.linspace(a.amin, a.amax, a.rays)
 y0 = fan_y0(arrs, 1000.0, 0.0, -theta)
 for mode in a.modes:
-    fan = DeviceFan(env, y0, 0.0, a.km * 1e3, a.S, save=(mode != "nosave"), sample_major=(mode == "sample"), exact_bisection=a.exact)
+    fan = DeviceFan(env, y0, 0.0, a.km * 1e3, a.S, save=(mode != "nosave"), sample_major=(mode == "sample"), exact_bisection=a.exact, exact_samples=a.exact_samples)
     for w, (pl, pt) in [(w, pp) for w in a.wpb for pp in zip(a.park[0::2], a.park[1::2])]:
         _lib.set_waves_per_block(w)
         _lib.set_park(pl, pt)

@@ -251,6 +251,29 @@ def test_layouts_and_end_state_only(lib):
         lib.EnvHandle(arrs[0], arrs[1], arrs[2], arrs[3], arrs[4][:3], arrs[5][:3], arrs[6][:3])
 
 
+def test_sample_evaluation_orders_agree(lib):
+    """Default (stage-major FMA) and PGR_EXACT_SAMPLES (SciPy's Q = K.T @ P order) evaluate
+    the SAME quartics of the SAME integration: steps, end states and the exact last column are
+    bit-identical, interior samples differ by rounding only (they never feed back)."""
+    arrs = munk_arrays(300e3)
+    env = lib.EnvHandle(*arrs)
+    S = 301
+    for lo, hi in ((-10, 10), (-20, 20)):   # without / with bounces
+        y0 = y0_for(oracle, arrs, 1000.0, 0.0, np.linspace(lo, hi, 333))
+        a = env.shoot_fan(y0, 0.0, 300e3, S)
+        b = env.shoot_fan(y0, 0.0, 300e3, S, exact_samples=True)
+        assert np.array_equal(a["end"], b["end"], equal_nan=True)
+        assert np.array_equal(a["n_steps"], b["n_steps"]) and np.array_equal(a["status"], b["status"])
+        ok = a["status"] == 0
+        for nm, scale in (("T", 300e3 / 1500.0), ("z", 5000.0), ("p", 1 / 1500.0)):
+            assert np.array_equal(a[nm][ok, -1], b[nm][ok, -1])
+            d = np.abs(a[nm][ok] - b[nm][ok]) / scale
+            assert np.median(d) < 1e-15, (nm, np.median(d))
+            # the stage-major form is used inside a step only (0 <= xi <= 1); the extrapolated
+            # end-of-segment samples (Q5) keep SciPy's order and are bit-identical
+            assert d.max() < 1e-12, (nm, d.max())
+
+
 # ------------------------------------------------------------------ full size: size-independent properties
 def test_full_size_config1_properties(lib):
     """BASELINE configs[1] at full size (1e5 rays, 1000 km): the oracle cannot run this in
