@@ -47,22 +47,38 @@ def munk_tables(r_max, nr=100):
     return env, _unpack_envi(env, flatearth=False)
 
 
-def cpu_baseline(arrs, n_rays=12500):
-    """CPU oracle (C port of the reference integrator, OpenMP over rays) on a bounded sample:
-    every (100000/n_rays)-th ray of the same fan, full 1000 km, end-state + trajectories."""
+def host_cores():
+    """Cores this process may really use: min(affinity, cgroup CPU quota)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(arrs, n_rays=25000):
+    """CPU oracle (C port of the reference integrator, OpenMP over rays, one thread per usable
+    core) on a bounded sample: every (100000/n_rays)-th ray of the same fan, full 1000 km,
+    trajectories included (about 30 core-seconds)."""
     import oracle
     from pygenray_amd.device_fan import fan_y0
     theta = np.linspace(-20, 20, RAYS_PER_GPU)[:: RAYS_PER_GPU // n_rays][:n_rays]
     y0 = fan_y0(arrs, SOURCE_DEPTH, 0.0, -theta)
     oracle.lib()
+    cores = host_cores()
+    oracle.set_num_threads(cores)
     t0 = time.time()
     out = oracle.shoot_fan(*arrs, y0, 0.0, RANGE_M, S_SAVE)
     dt = time.time() - t0
     steps = int(out["n_steps"].sum())
-    return {"value": steps / dt, "unit": "ray-steps/s", "cores": oracle.num_threads(),
+    return {"value": steps / dt, "unit": "ray-steps/s", "cores": cores,
             "kind": "port",
             "sample": f"{len(y0)} rays (every {RAYS_PER_GPU // n_rays}th of the 1e5-ray fan), "
-                      f"1000 km, {steps} ray-steps in {dt:.1f} s, oracle/ray_oracle.c with OpenMP"}
+                      f"1000 km, {steps} ray-steps in {dt:.1f} s, oracle/ray_oracle.c with OpenMP, "
+                      f"{cores} threads (cgroup CPU quota of the box)"}
 
 
 def scipy_baseline(arrs, n_rays=12):
@@ -107,7 +123,10 @@ def main():
         if rank == 0 and world > 1:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # PGR_BENCH_FORCE_DIST=1 rehearses the N > 1 code path (RCCL init, all-gather, reductions)
+    # with a single rank on a one-GPU box
+    use_dist = world > 1 or os.environ.get("PGR_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -125,13 +144,13 @@ def main():
 
     def step():
         fan.run()
-        if world > 1:
+        if use_dist:
             return all_gather_fan(fan.end, fan.n_bott, fan.n_surf, fan.status, n_global)
         return None
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -145,14 +164,14 @@ def main():
         ev[k][0].record()
         fan.run()
         ev[k][1].record()
-        if world > 1:
+        if use_dist:
             all_gather_fan(fan.end, fan.n_bott, fan.n_surf, fan.status, n_global)
     fence()
     dt = time.perf_counter() - t0
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     local_steps = fan.ray_steps()
     n_drop = int((fan.status != 0).sum().item())
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -205,7 +224,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(arrs)
             out["cpu_baseline_scipy"] = scipy_baseline(arrs)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -114,6 +114,11 @@ def num_threads():
     return lib().orc_num_threads()
 
 
+def set_num_threads(n):
+    """OpenMP threads used by shoot_fan (bench.py sizes this to the cores the process may use)."""
+    lib().orc_set_num_threads(int(n))
+
+
 def shoot_fan(cin, cpin, rin, zin, depths, depth_ranges, bottom_angles, y0, source_range,
               receiver_range, num_range_save, rtol=1e-9, atol=1e-6, terminate_backwards=True,
               max_steps=10_000_000):

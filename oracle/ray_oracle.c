@@ -657,6 +657,15 @@ void orc_events(const double *cin, const double *rin, const double *zin, int64_t
     orc_env e = {cin, 0, rin, zin, nr, nz, depths, depth_ranges, 0, nb, 0};
     for (int k = 0; k < 4; k++) out4[k] = EVENTS[k](&e, x, y);
 }
+void orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    extern void omp_set_num_threads(int);
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 int orc_num_threads(void)
 {
 #ifdef _OPENMP

@@ -39,7 +39,7 @@ def all_gather_fan(end, n_bott, n_surf, status, n_rays, group=None):
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     n_pad = (n_rays + world - 1) // world
     local = pack_end_records(end, n_bott, n_surf, status, n_pad)
-    if world > 1:
+    if dist.is_initialized():  # also with a single rank: the collective is then a copy
         flat = torch.empty((world * n_pad, 5), dtype=torch.float64, device=local.device)
         dist.all_gather_into_tensor(flat, local, group=group)
         gathered = flat.view(world, n_pad, 5)

@@ -1,0 +1,50 @@
+"""Turn the rocprofv3 outputs of scripts/collect_profiles.sh (merged back under gpurun_out/) into
+the committed summaries: profiles/<round>_kernel_stats.csv and profiles/<round>_traffic.json.
+usage: python scripts/summarize_profiles.py <tag> <round>   e.g.  prof4 r01"""
+import csv, glob, json, os, shutil, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, rnd = sys.argv[1], sys.argv[2]
+G = os.path.join(ROOT, "gpurun_out")
+
+
+def fan_counters(d):
+    f = glob.glob(os.path.join(G, d, "*", "*_counter_collection.csv"))
+    if not f:
+        return {}
+    per = {}
+    for r in csv.DictReader(open(f[0])):
+        if "pgr_fan_kernel" in r["Kernel_Name"]:
+            per.setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
+            per[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+    # last dispatch of the fan kernel (a timed step, not the warm-up)
+    return {k: v[sorted(v, key=int)[-1]] for k, v in per.items()}
+
+
+out = {}
+for key, pre in (("sample", ""), ("sample-nosave", "nosave_")):
+    fe = fan_counters(f"{tag}_{pre}FETCH_SIZE").get("FETCH_SIZE")
+    wr = fan_counters(f"{tag}_{pre}WRITE_SIZE").get("WRITE_SIZE")
+    if fe is None or wr is None:
+        continue
+    # MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KB; gfx950 FETCH_SIZE counts half the bytes
+    out[key] = {"rays": 100000, "FETCH_SIZE_KB": fe, "WRITE_SIZE_KB": wr,
+                "hbm_gb_per_launch": (2 * fe + wr) * 1024 / 1e9,
+                "command": f"rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- "
+                           f"python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline{' --no-save' if pre else ''}"}
+sq = fan_counters(f"{tag}_sq")
+if sq:
+    out["sq_counters_sample"] = sq
+old = os.path.join(ROOT, "profiles", f"{rnd}_traffic.json")
+if os.path.exists(old):
+    prev = json.load(open(old))
+    for k in ("ray", "ray-nosave"):
+        if k in prev and k not in out:
+            out[k] = prev[k]
+out["_note"] = f"{rnd}: fan kernel, last dispatch of each pass; 'ray' rows (if present) measured earlier in the round with the [N][S] layout"
+json.dump(out, open(old, "w"), indent=1)
+st = glob.glob(os.path.join(G, f"{tag}_stats", "*", "*_kernel_stats.csv"))
+if st:
+    shutil.copy(st[0], os.path.join(ROOT, "profiles", f"{rnd}_kernel_stats.csv"))
+print(json.dumps(out, indent=1))
+if st:
+    print(open(st[0]).read())
