@@ -160,13 +160,15 @@ __device__ __forceinline__ double frsqrt_raw(double x)
 __device__ __forceinline__ double fsqrt(double x)
 {
 #if PGR_FAST
-    if (!(x > 0)) return (x == 0) ? 0.0 : sqrt(x);
     double y = __builtin_amdgcn_rsq(x);  // good to 5.2e-8: one Newton step, then the residual
     double e = fma(-x * y, y, 1.0);
     y = fma(y * 0.5, e, y);
     double g = x * y;
     double d = fma(-g, g, x);
-    return fma(d * 0.5, y, g);
+    double r = fma(d * 0.5, y, g);
+    // no branch: sqrt(+-0) = +-0 and sqrt(inf) = inf by select (rsq gives inf / 0 there and the
+    // refinement NaN); x < 0 and NaN come out NaN by themselves
+    return (x == 0.0 || x == INFINITY) ? x : r;
 #else
     return sqrt(x);
 #endif
@@ -403,16 +405,21 @@ struct Ctx {
     __device__ __forceinline__ unsigned events(double x, double z, double pz, double c) const
     {
         double pc = pz * c;
-        unsigned g = 0;
-        if ((z < 0) && (pc < 0) && (pc >= -1.0)) g |= 1u;
+        unsigned g = ((z < 0) & (pc < 0) & (pc >= -1.0)) ? 1u : 0u;
         // bottom: z > bathy(x) is impossible while z is above the shallowest bathymetry node
-        // (minus a margin for the interpolation's rounding) and x is inside the bathymetry table
-        if ((pc > 0) && (pc <= 1.0) && !(z < e.b_zmin && x >= e.b_xlo && x <= e.b_xhi)) {
-            if (z > bathy(x)) g |= 2u;
-        }
-        if (fabs(pc) > 0.9999999998 && fabs(pc) <= 1.0) {
-            double th = asin(pc) * (180.0 / M_PI);
-            if (fabs(th) > (90 - 1e-3)) g |= 4u;
+        // (minus a margin for the interpolation's rounding) and x is inside the bathymetry table;
+        // vertical: only |pc| within 2e-10 of 1 can reach 90 - 1e-3 degrees.  Both tests sit in ONE
+        // rarely entered block: every skipped block is a taken branch on the step's critical path.
+        const bool near_bottom = (pc > 0) & (pc <= 1.0) & !((z < e.b_zmin) & (x >= e.b_xlo) & (x <= e.b_xhi));
+        const bool near_vertical = (fabs(pc) > 0.9999999998) & (fabs(pc) <= 1.0);
+        if (near_bottom | near_vertical) {
+            if (near_bottom) {
+                if (z > bathy(x)) g |= 2u;
+            }
+            if (near_vertical) {
+                double th = asin(pc) * (180.0 / M_PI);
+                if (fabs(th) > (90 - 1e-3)) g |= 4u;
+            }
         }
         if ((z > e.zhi_tol) | (z < e.zlo_tol) | (x < e.rlo_tol) | (x > e.rhi_tol)) g |= 8u;
         return g;
@@ -884,34 +891,24 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
             double er2 = fdiv((f2 * E1 + k32 * E3 + k42 * E4 + k52 * E5 + k62 * E6 + k72 * E7) * h, sc2);
             double error_norm = rms3(er0, er1, er2);
 
-            bool accepted = false;
-            if (too_small) {
-                status = PGR_RAY_STEP_TOO_SMALL;
-            } else if (error_norm < 1) {
-                double factor;
-                // min(MAX_FACTOR, SAFETY * err^-0.2): the clamp is active below (0.09)^5 = 5.9e-6
-                if (error_norm < 5.0e-6) {
-                    factor = MAX_FACTOR;
-                } else {
-                    factor = SAFETY * pow_m02(error_norm);
-                    if (!(factor < MAX_FACTOR)) factor = MAX_FACTOR;
-                }
-                if (rejected && !(factor < 1)) factor = 1;
-                h_abs *= factor;
-                accepted = true;
-                rejected = false;
-            } else {
-                // max(MIN_FACTOR, SAFETY * err^-0.2): the clamp is active above 4.5^5 = 1845 (and for NaN)
-                double fac = MIN_FACTOR;
-                if (error_norm < 1800.0) {
-                    fac = SAFETY * pow_m02(error_norm);
-                    if (!(fac > MIN_FACTOR)) fac = MIN_FACTOR;
-                }
-                h_abs *= fac;
-                rejected = true;
-                n_rej++;
-                if ((int64_t)n_rej + n_steps > 4 * a.max_steps + 4096) status = PGR_RAY_MAX_STEPS;
-            }
+            // ---- accept / reject and the next step size, SCIPY/rk.py:148-165, without branches: a
+            // taken skip-branch costs a lone in-order wave ~80 cycles (scripts/probes/branch_probe2),
+            // as much as 20 fp64 operations, and the slowest wave's latency is the fan's run time.
+            // ONE err^-0.2 serves both outcomes; where SciPy's min/max clamp decides (or the power
+            // is not finite: err = 0, NaN) the select takes the constant:
+            //   accept: min(MAX_FACTOR, SAFETY err^-0.2), the clamp is active below 0.09^5 = 5.9e-6
+            //   reject: max(MIN_FACTOR, SAFETY err^-0.2), the clamp is active above 4.5^5 = 1845, NaN
+            const bool accepted = !too_small && (error_norm < 1);
+            const bool reject = !too_small && !accepted;
+            const double pw = SAFETY * pow_m02(error_norm);
+            double fac_acc = (error_norm < 5.0e-6) ? MAX_FACTOR : ((pw < MAX_FACTOR) ? pw : MAX_FACTOR);
+            fac_acc = (rejected && !(fac_acc < 1)) ? 1.0 : fac_acc;
+            const double fac_rej = (error_norm < 1800.0) ? ((pw > MIN_FACTOR) ? pw : MIN_FACTOR) : MIN_FACTOR;
+            h_abs = too_small ? h_abs : h_abs * (accepted ? fac_acc : fac_rej);
+            rejected = too_small ? rejected : reject;
+            n_rej += reject ? 1 : 0;
+            status = too_small ? PGR_RAY_STEP_TOO_SMALL
+                               : ((reject && ((int64_t)n_rej + n_steps > 4 * a.max_steps + 4096)) ? PGR_RAY_MAX_STEPS : status);
 
             if (accepted) {
                 n_steps++;
@@ -927,11 +924,9 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                 // owns, Q5, |xi| up to 1e5) amplify rounding by xi^4 and keep SciPy's order
                 const bool scipy_order = exact_samples || (rnext < t);
                 Dense D;
-                if (active || (want_samples && scipy_order)) {
-                    PGR_FORM_Q();
-                }
                 if (active) {
                     // park: the step is located, truncated and bounced in the next service phase
+                    PGR_FORM_Q();
                     parked = true;
                     pk_active = active;
                     pk_tnew = t_new;
@@ -945,6 +940,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                     // segment slice [idx1, idx2) that this step's quartic owns ----
                     if (want_samples) {
                         if (scipy_order) {
+                            PGR_FORM_Q();
                             while (jnext < S - 1 && rnext <= t_new) {
                                 double o0, o1, o2;
                                 D.eval(t, y0, y1, y2, rnext, o0, o1, o2);
