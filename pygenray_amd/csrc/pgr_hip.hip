@@ -255,6 +255,40 @@ __device__ __forceinline__ int cell_search(double q, const double* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------
+// Dormand-Prince coefficients, SCIPY/rk.py:377-404
+// ------------------------------------------------------------------------------------
+#define A21 (1.0 / 5)
+#define A31 (3.0 / 40)
+#define A32 (9.0 / 40)
+#define A41 (44.0 / 45)
+#define A42 (-56.0 / 15)
+#define A43 (32.0 / 9)
+#define A51 (19372.0 / 6561)
+#define A52 (-25360.0 / 2187)
+#define A53 (64448.0 / 6561)
+#define A54 (-212.0 / 729)
+#define A61 (9017.0 / 3168)
+#define A62 (-355.0 / 33)
+#define A63 (46732.0 / 5247)
+#define A64 (49.0 / 176)
+#define A65 (-5103.0 / 18656)
+#define B1 (35.0 / 384)
+#define B3 (500.0 / 1113)
+#define B4 (125.0 / 192)
+#define B5 (-2187.0 / 6784)
+#define B6 (11.0 / 84)
+#define E1 (-71.0 / 57600)
+#define E3 (71.0 / 16695)
+#define E4 (-71.0 / 1920)
+#define E5 (17253.0 / 339200)
+#define E6 (-22.0 / 525)
+#define E7 (1.0 / 40)
+#define C2 (1.0 / 5)
+#define C3 (3.0 / 10)
+#define C4 (4.0 / 5)
+#define C5 (8.0 / 9)
+
+// ------------------------------------------------------------------------------------
 // per-kernel context: where table nodes come from
 // ------------------------------------------------------------------------------------
 // ZS ("z simple"): zin[j] == j*dz bitwise with dz a power of two and zin[0] == 0 (e.g. the
@@ -266,7 +300,7 @@ struct Ctx {
     const double2* lds;  // LDS copy of the (single) depth profile when LDS_TAB
     // per-lane caches: x only moves forward, so the range cell (and the bathymetry cell under
     // the ray) changes once every ~10 km; keep its edges and the reciprocal of its width
-    mutable double r_lo, r_hi, r_yden;
+    mutable double r_lo, r_hi, r_yden, r_hi2;  // r_hi2: upper edge of the NEXT cell (uniform rin) or r_hi
     mutable int r_i;
     // wave-uniform copies of the fields the step loop touches (kept in SGPRs; the rest of the
     // descriptor is read from memory where it is needed)
@@ -277,7 +311,7 @@ struct Ctx {
         : e(e_), lds(l), h_inv_dz(e_.inv_dz), h_dz(e_.dz), h_r0(e_.r0), h_dr(e_.dr),
           h_inv_dr(e_.inv_dr), h_rin(e_.rin), h_nz(e_.nz), h_nr(e_.nr), h_r_uniform(e_.r_uniform)
     {
-        r_lo = 1.0; r_hi = 0.0; r_yden = 1.0; r_i = 0;  // empty interval: first use refills
+        r_lo = 1.0; r_hi = 0.0; r_yden = 1.0; r_hi2 = 0.0; r_i = 0;  // empty interval: first use refills
     }
 
     __device__ __forceinline__ int cell_z(double z, double& zj, double& zj1) const
@@ -308,15 +342,18 @@ struct Ctx {
         }
         return i;
     }
+    __device__ __forceinline__ void refill(double x) const
+    {
+        double ri, ri1;
+        r_i = cell_r(x, ri, ri1);
+        r_lo = ri; r_hi = ri1;
+        r_yden = frcp(ri1 - ri);
+        r_hi2 = (h_r_uniform && r_i + 2 <= h_nr - 1) ? grid_at(h_r0, h_dr, r_i + 2) : ri1;
+    }
     // wx = (x - rin[i]) / (rin[i+1] - rin[i]) through the cached cell
     __device__ __forceinline__ double weight_r(double x, int& i) const
     {
-        if (!(x > r_lo && x <= r_hi)) {
-            double ri, ri1;
-            r_i = cell_r(x, ri, ri1);
-            r_lo = ri; r_hi = ri1;
-            r_yden = frcp(ri1 - ri);
-        }
+        if (!(x > r_lo && x <= r_hi)) refill(x);
         i = r_i;
 #if PGR_FAST
         return fdiv_y(x - r_lo, r_hi - r_lo, r_yden);
@@ -328,8 +365,14 @@ struct Ctx {
     // bilinear c and dc/dz at (x, z): REF/integration_processes.py:101-174, both tables at once
     __device__ __forceinline__ void lookup(double x, double z, double& c, double& cp) const
     {
-        int i, j;
+        int i;
         double wx = weight_r(x, i);
+        lookup_w(wx, i, z, c, cp);
+    }
+    // the same with the range weight and range cell already known (step_weights)
+    __device__ __forceinline__ void lookup_w(double wx, int i, double z, double& c, double& cp) const
+    {
+        int j;
         double wy;
         if (ZS) {
             double t = z * h_inv_dz;                     // exact
@@ -382,8 +425,15 @@ struct Ctx {
     __device__ __forceinline__ void rhs(double x, double z, double pz, double& d0, double& d1,
                                         double& d2, double& c) const
     {
+        int i;
+        double wx = weight_r(x, i);
+        rhs_w(wx, i, z, pz, d0, d1, d2, c);
+    }
+    __device__ __forceinline__ void rhs_w(double wx, int i, double z, double pz, double& d0, double& d1,
+                                          double& d2, double& c) const
+    {
         double cp;
-        lookup(x, z, c, cp);
+        lookup_w(wx, i, z, c, cp);
         double arg = 1.0 - (c * c) * (pz * pz);
         if (arg <= 0.0) arg = 1e-30;
 #if PGR_FAST
@@ -398,6 +448,56 @@ struct Ctx {
         d1 = c * pz * fact;
         d2 = -fact * cp / (c * c);
 #endif
+    }
+
+    // Range weights (and cells) of the five stage abscissae x_s = t + C_s h of ONE step attempt,
+    // C = (1/5, 3/10, 4/5, 8/9, 1), bitwise what weight_r(x_s) returns.  x only moves forward and a
+    // step is short against a range cell, so nearly always every x_s lies in the cached cell: five
+    // multiplies by the cached reciprocal, no test per stage (a skipped refill block is a taken
+    // branch: ~80 cycles, six per trip).  Steps that straddle the cell's upper edge take ONE block
+    // per attempt: uniform rin -> the next cell is known in closed form and each x_s selects its
+    // cell; anything else (non-uniform rin, a step wider than two cells, a cache that an event
+    // search left elsewhere) goes stage by stage through weight_r.
+    __device__ __forceinline__ void step_weights(double t, double h, double (&w)[5], int (&ic)[5]) const
+    {
+        const double xs[5] = {t + C2 * h, t + C3 * h, t + C4 * h, t + C5 * h, t + 1.0 * h};
+        if (__builtin_expect((t >= r_lo) & (xs[4] <= r_hi), 1)) {
+            const double den = r_hi - r_lo;
+#pragma unroll
+            for (int s = 0; s < 5; s++) {
+#if PGR_FAST
+                w[s] = fdiv_y(xs[s] - r_lo, den, r_yden);
+#else
+                w[s] = (xs[s] - r_lo) / den;
+#endif
+                ic[s] = r_i;
+            }
+        } else {
+            // the committed t has left the cached cell: step the cache to the next cell
+            if (h_r_uniform && (t > r_hi) && (t <= r_hi2) && (r_hi2 > r_hi)) {
+                r_lo = r_hi; r_hi = r_hi2; r_i++;
+                r_yden = frcp(r_hi - r_lo);
+                r_hi2 = (r_i + 2 <= h_nr - 1) ? grid_at(h_r0, h_dr, r_i + 2) : r_hi;
+            }
+            if (h_r_uniform && (t >= r_lo) && (t <= r_hi) && (xs[4] <= r_hi2)) {
+                const double a_den = r_hi - r_lo, b_den = r_hi2 - r_hi;
+                const double b_yden = frcp(b_den);
+#pragma unroll
+                for (int s = 0; s < 5; s++) {
+                    const bool in_b = xs[s] > r_hi;
+                    const double lo = in_b ? r_hi : r_lo, den = in_b ? b_den : a_den, yd = in_b ? b_yden : r_yden;
+#if PGR_FAST
+                    w[s] = fdiv_y(xs[s] - lo, den, yd);
+#else
+                    w[s] = (xs[s] - lo) / den;
+#endif
+                    ic[s] = r_i + (in_b ? 1 : 0);
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 5; s++) w[s] = weight_r(xs[s], ic[s]);
+            }
+        }
     }
 
     // the four +-1 events (REF/integration_processes.py:238-303) as a bit mask, bit k = event
@@ -425,40 +525,6 @@ struct Ctx {
         return g;
     }
 };
-
-// ------------------------------------------------------------------------------------
-// Dormand-Prince coefficients, SCIPY/rk.py:377-404
-// ------------------------------------------------------------------------------------
-#define A21 (1.0 / 5)
-#define A31 (3.0 / 40)
-#define A32 (9.0 / 40)
-#define A41 (44.0 / 45)
-#define A42 (-56.0 / 15)
-#define A43 (32.0 / 9)
-#define A51 (19372.0 / 6561)
-#define A52 (-25360.0 / 2187)
-#define A53 (64448.0 / 6561)
-#define A54 (-212.0 / 729)
-#define A61 (9017.0 / 3168)
-#define A62 (-355.0 / 33)
-#define A63 (46732.0 / 5247)
-#define A64 (49.0 / 176)
-#define A65 (-5103.0 / 18656)
-#define B1 (35.0 / 384)
-#define B3 (500.0 / 1113)
-#define B4 (125.0 / 192)
-#define B5 (-2187.0 / 6784)
-#define B6 (11.0 / 84)
-#define E1 (-71.0 / 57600)
-#define E3 (71.0 / 16695)
-#define E4 (-71.0 / 1920)
-#define E5 (17253.0 / 339200)
-#define E6 (-22.0 / 525)
-#define E7 (1.0 / 40)
-#define C2 (1.0 / 5)
-#define C3 (3.0 / 10)
-#define C4 (4.0 / 5)
-#define C5 (8.0 / 9)
 
 __device__ __forceinline__ double rms3(double a, double b, double c)
 {
@@ -612,6 +678,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     const int S = a.S;
     const bool save = (a.T != nullptr);
     const bool exact_samples = (a.flags & PGR_EXACT_SAMPLES) != 0;
+    const int64_t attempt_limit = 4 * a.max_steps + 4096;  // guard against endless rejection
     SaveGrid G;
     G.r = a.r_save; G.x0 = a.x0; G.x1 = a.x1; G.step = a.save_step; G.inv_step = a.inv_dsave;
     G.S = S; G.formula = a.save_formula;
@@ -866,22 +933,25 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
             // rk_step, SCIPY/rk.py:14-71 (K1 = f by FSAL)
             double k20, k21, k22, k30, k31, k32, k40, k41, k42, k50, k51, k52, k60, k61, k62, k70,
                 k71, k72, cs;
-            C.rhs(t + C2 * h, y1 + (f1 * A21) * h, y2 + (f2 * A21) * h, k20, k21, k22, cs);
-            C.rhs(t + C3 * h, y1 + (f1 * A31 + k21 * A32) * h, y2 + (f2 * A31 + k22 * A32) * h, k30,
-                  k31, k32, cs);
-            C.rhs(t + C4 * h, y1 + (f1 * A41 + k21 * A42 + k31 * A43) * h,
-                  y2 + (f2 * A41 + k22 * A42 + k32 * A43) * h, k40, k41, k42, cs);
-            C.rhs(t + C5 * h, y1 + (f1 * A51 + k21 * A52 + k31 * A53 + k41 * A54) * h,
-                  y2 + (f2 * A51 + k22 * A52 + k32 * A53 + k42 * A54) * h, k50, k51, k52, cs);
-            C.rhs(t + 1.0 * h, y1 + (f1 * A61 + k21 * A62 + k31 * A63 + k41 * A64 + k51 * A65) * h,
-                  y2 + (f2 * A61 + k22 * A62 + k32 * A63 + k42 * A64 + k52 * A65) * h, k60, k61, k62,
-                  cs);
+            double wr[5];
+            int ir[5];
+            C.step_weights(t, h, wr, ir);
+            C.rhs_w(wr[0], ir[0], y1 + (f1 * A21) * h, y2 + (f2 * A21) * h, k20, k21, k22, cs);
+            C.rhs_w(wr[1], ir[1], y1 + (f1 * A31 + k21 * A32) * h, y2 + (f2 * A31 + k22 * A32) * h, k30,
+                    k31, k32, cs);
+            C.rhs_w(wr[2], ir[2], y1 + (f1 * A41 + k21 * A42 + k31 * A43) * h,
+                    y2 + (f2 * A41 + k22 * A42 + k32 * A43) * h, k40, k41, k42, cs);
+            C.rhs_w(wr[3], ir[3], y1 + (f1 * A51 + k21 * A52 + k31 * A53 + k41 * A54) * h,
+                    y2 + (f2 * A51 + k22 * A52 + k32 * A53 + k42 * A54) * h, k50, k51, k52, cs);
+            C.rhs_w(wr[4], ir[4], y1 + (f1 * A61 + k21 * A62 + k31 * A63 + k41 * A64 + k51 * A65) * h,
+                    y2 + (f2 * A61 + k22 * A62 + k32 * A63 + k42 * A64 + k52 * A65) * h, k60, k61, k62,
+                    cs);
             // y_new = y + h * (K[:-1].T @ B)   (B[1] = 0)
             double n0 = y0 + h * (f0 * B1 + k30 * B3 + k40 * B4 + k50 * B5 + k60 * B6);
             double n1 = y1 + h * (f1 * B1 + k31 * B3 + k41 * B4 + k51 * B5 + k61 * B6);
             double n2 = y2 + h * (f2 * B1 + k32 * B3 + k42 * B4 + k52 * B5 + k62 * B6);
             double c_new;
-            C.rhs(t + h, n1, n2, k70, k71, k72, c_new);
+            C.rhs_w(wr[4], ir[4], n1, n2, k70, k71, k72, c_new);  // f_new at t + h: the stage-6 abscissa
             // error estimate, SCIPY/rk.py:106-110,146-147  (E[1] = 0)
             double sc0 = atol + fmax(fabs(y0), fabs(n0)) * rtol;
             double sc1 = atol + fmax(fabs(y1), fabs(n1)) * rtol;
@@ -907,8 +977,8 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
             h_abs = too_small ? h_abs : h_abs * (accepted ? fac_acc : fac_rej);
             rejected = too_small ? rejected : reject;
             n_rej += reject ? 1 : 0;
-            status = too_small ? PGR_RAY_STEP_TOO_SMALL
-                               : ((reject && ((int64_t)n_rej + n_steps > 4 * a.max_steps + 4096)) ? PGR_RAY_MAX_STEPS : status);
+            const bool over = (int64_t)((unsigned)n_rej + (unsigned)n_steps) > attempt_limit;
+            status = too_small ? PGR_RAY_STEP_TOO_SMALL : ((reject & over) ? PGR_RAY_MAX_STEPS : status);
 
             if (accepted) {
                 n_steps++;
