@@ -709,8 +709,152 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
 #define Zp (a.Z + out_off)
 #define Pp (a.P + out_off)
 
-    while (__any(status == RUNNING)) {
+    // One trip = one step attempt of every stepping lane, THEN the gate that decides whether the
+    // wave services its parked lanes.  (The first trip only runs the gate: every lane starts with
+    // need_init.)  The step comes first so that the common path -- nobody parked -- is the loop's
+    // fall-through: one skipped block and the back-edge are its only taken branches.
+    do {
         trips++;
+        if (status == RUNNING && !parked && !need_init) {
+            // ---- one attempt of RK45._step_impl, SCIPY/rk.py:111-176 ----
+            double min_step = min_step_of(t);
+            if (!rejected && h_abs < min_step) h_abs = min_step;  // clamp only on entry
+            bool too_small = h_abs < min_step;
+            double h = h_abs;
+            double t_new = t + h;
+            if ((t_new - t_bound) > 0) t_new = t_bound;
+            h = t_new - t;
+            h_abs = fabs(h);
+
+            // rk_step, SCIPY/rk.py:14-71 (K1 = f by FSAL)
+            double k20, k21, k22, k30, k31, k32, k40, k41, k42, k50, k51, k52, k60, k61, k62, k70,
+                k71, k72, cs;
+            double wr[5];
+            int ir[5];
+            C.step_weights(t, h, wr, ir);
+            C.rhs_w(wr[0], ir[0], y1 + (f1 * A21) * h, y2 + (f2 * A21) * h, k20, k21, k22, cs);
+            C.rhs_w(wr[1], ir[1], y1 + (f1 * A31 + k21 * A32) * h, y2 + (f2 * A31 + k22 * A32) * h, k30,
+                    k31, k32, cs);
+            C.rhs_w(wr[2], ir[2], y1 + (f1 * A41 + k21 * A42 + k31 * A43) * h,
+                    y2 + (f2 * A41 + k22 * A42 + k32 * A43) * h, k40, k41, k42, cs);
+            C.rhs_w(wr[3], ir[3], y1 + (f1 * A51 + k21 * A52 + k31 * A53 + k41 * A54) * h,
+                    y2 + (f2 * A51 + k22 * A52 + k32 * A53 + k42 * A54) * h, k50, k51, k52, cs);
+            C.rhs_w(wr[4], ir[4], y1 + (f1 * A61 + k21 * A62 + k31 * A63 + k41 * A64 + k51 * A65) * h,
+                    y2 + (f2 * A61 + k22 * A62 + k32 * A63 + k42 * A64 + k52 * A65) * h, k60, k61, k62,
+                    cs);
+            // y_new = y + h * (K[:-1].T @ B)   (B[1] = 0)
+            double n0 = y0 + h * (f0 * B1 + k30 * B3 + k40 * B4 + k50 * B5 + k60 * B6);
+            double n1 = y1 + h * (f1 * B1 + k31 * B3 + k41 * B4 + k51 * B5 + k61 * B6);
+            double n2 = y2 + h * (f2 * B1 + k32 * B3 + k42 * B4 + k52 * B5 + k62 * B6);
+            double c_new;
+            C.rhs_w(wr[4], ir[4], n1, n2, k70, k71, k72, c_new);  // f_new at t + h: the stage-6 abscissa
+            // error estimate, SCIPY/rk.py:106-110,146-147  (E[1] = 0)
+            double sc0 = atol + fmax(fabs(y0), fabs(n0)) * rtol;
+            double sc1 = atol + fmax(fabs(y1), fabs(n1)) * rtol;
+            double sc2 = atol + fmax(fabs(y2), fabs(n2)) * rtol;
+            double er0 = fdiv((f0 * E1 + k30 * E3 + k40 * E4 + k50 * E5 + k60 * E6 + k70 * E7) * h, sc0);
+            double er1 = fdiv((f1 * E1 + k31 * E3 + k41 * E4 + k51 * E5 + k61 * E6 + k71 * E7) * h, sc1);
+            double er2 = fdiv((f2 * E1 + k32 * E3 + k42 * E4 + k52 * E5 + k62 * E6 + k72 * E7) * h, sc2);
+            double error_norm = rms3(er0, er1, er2);
+
+            // ---- accept / reject and the next step size, SCIPY/rk.py:148-165, without branches: a
+            // taken skip-branch costs a lone in-order wave ~80 cycles (scripts/probes/branch_probe2),
+            // as much as 20 fp64 operations, and the slowest wave's latency is the fan's run time.
+            // ONE err^-0.2 serves both outcomes; where SciPy's min/max clamp decides (or the power
+            // is not finite: err = 0, NaN) the select takes the constant:
+            //   accept: min(MAX_FACTOR, SAFETY err^-0.2), the clamp is active below 0.09^5 = 5.9e-6
+            //   reject: max(MIN_FACTOR, SAFETY err^-0.2), the clamp is active above 4.5^5 = 1845, NaN
+            const bool accepted = !too_small && (error_norm < 1);
+            const bool reject = !too_small && !accepted;
+            const double pw = SAFETY * pow_m02(error_norm);
+            double fac_acc = (error_norm < 5.0e-6) ? MAX_FACTOR : ((pw < MAX_FACTOR) ? pw : MAX_FACTOR);
+            fac_acc = (rejected && !(fac_acc < 1)) ? 1.0 : fac_acc;
+            const double fac_rej = (error_norm < 1800.0) ? ((pw > MIN_FACTOR) ? pw : MIN_FACTOR) : MIN_FACTOR;
+            h_abs = too_small ? h_abs : h_abs * (accepted ? fac_acc : fac_rej);
+            rejected = too_small ? rejected : reject;
+            n_rej += reject ? 1 : 0;
+            const bool over = (int64_t)((unsigned)n_rej + (unsigned)n_steps) > attempt_limit;
+            status = too_small ? PGR_RAY_STEP_TOO_SMALL : ((reject & over) ? PGR_RAY_MAX_STEPS : status);
+
+            if (accepted) {
+                n_steps++;
+                // events at the new point, SCIPY/ivp.py:671-675 (c at (t_new, y_new) is the FSAL lookup)
+                unsigned g_new = C.events(t_new, n1, n2, c_new);
+                // find_active_events, SCIPY/ivp.py:133-156: values are +-1, so "up" = -1 -> +1,
+                // "down" = +1 -> -1; surface/bottom need "up", vertical/bbox take either
+                unsigned up = (~g) & g_new, down = g & (~g_new);
+                unsigned active = (up & 3u) | ((up | down) & 12u);
+                g = g_new;
+                bool want_samples = save && (jnext < S - 1) && (rnext <= t_new);
+                // samples behind the step (rnext < t: the extrapolated ones a segment's first step
+                // owns, Q5, |xi| up to 1e5) amplify rounding by xi^4 and keep SciPy's order
+                const bool scipy_order = exact_samples || (rnext < t);
+                Dense D;
+                if (active) {
+                    // park: the step is located, truncated and bounced in the next service phase
+                    PGR_FORM_Q();
+                    parked = true;
+                    pk_active = active;
+                    pk_tnew = t_new;
+                    pk_lds[0] = D.h;
+#pragma unroll
+                    for (int i = 0; i < 3; i++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) pk_lds[(1 + 4 * i + j) * blockDim.x] = D.q[i][j];
+                } else {
+                    // ---- _interpolate_ray, streamed (REF/launch_rays.py:763-772, Q5): samples of the
+                    // segment slice [idx1, idx2) that this step's quartic owns ----
+                    if (want_samples) {
+                        if (scipy_order) {
+                            PGR_FORM_Q();
+                            while (jnext < S - 1 && rnext <= t_new) {
+                                double o0, o1, o2;
+                                D.eval(t, y0, y1, y2, rnext, o0, o1, o2);
+                                Tp[(int64_t)jnext * a.stride_smp] = o0;
+                                Zp[(int64_t)jnext * a.stride_smp] = o1;
+                                Pp[(int64_t)jnext * a.stride_smp] = o2;
+                                jnext++;
+                                rnext = G.at(jnext);
+                            }
+                        } else {
+                            // The same quartic summed stage-major, y_old + h * sum_j K_j b_j(xi) with
+                            // b_j(xi) = sum_k P[j][k] xi^(k+1), in FMAs: no Q = K.T @ P to form (a third
+                            // of the work) and a few ulp from SciPy's summation order.  Output samples
+                            // never feed back into the integration, so this cannot move a ray.
+                            const double inv_h = frcp(h);
+#define PGR_KSUM(k1, k3, k4, k5, k6, k7)                                                          \
+    __builtin_fma(k1, b1, __builtin_fma(k3, b3, __builtin_fma(k4, b4, __builtin_fma(k5, b5,      \
+                  __builtin_fma(k6, b6, (k7) * b7)))))
+#define PGR_SAMPLE_LOOP(NEXT)                                                                     \
+    while (jnext < S - 1 && rnext <= t_new) {                                                     \
+        const double xi = (rnext - t) * inv_h, x2 = xi * xi;                                      \
+        const double b1 = xi * __builtin_fma(xi, __builtin_fma(xi, __builtin_fma(xi, P13, P12), P11), P10); \
+        const double b3 = x2 * __builtin_fma(xi, __builtin_fma(xi, P33, P32), P31);               \
+        const double b4 = x2 * __builtin_fma(xi, __builtin_fma(xi, P43, P42), P41);               \
+        const double b5 = x2 * __builtin_fma(xi, __builtin_fma(xi, P53, P52), P51);               \
+        const double b6 = x2 * __builtin_fma(xi, __builtin_fma(xi, P63, P62), P61);               \
+        const double b7 = x2 * __builtin_fma(xi, __builtin_fma(xi, P73, P72), P71);               \
+        Tp[(int64_t)jnext * a.stride_smp] = __builtin_fma(h, PGR_KSUM(f0, k30, k40, k50, k60, k70), y0); \
+        Zp[(int64_t)jnext * a.stride_smp] = __builtin_fma(h, PGR_KSUM(f1, k31, k41, k51, k61, k71), y1); \
+        Pp[(int64_t)jnext * a.stride_smp] = __builtin_fma(h, PGR_KSUM(f2, k32, k42, k52, k62, k72), y2); \
+        jnext++;                                                                                  \
+        rnext = NEXT;                                                                             \
+    }
+                            // two copies so that the linspace one holds no load: a load in the loop
+                            // makes every iteration wait (vmcnt) for the stores of the one before
+                            if (G.formula) { PGR_SAMPLE_LOOP(((jnext >= S - 1) ? G.x1 : grid_at(G.x0, G.step, jnext))) }
+                            else { PGR_SAMPLE_LOOP(G.r[jnext]) }
+#undef PGR_SAMPLE_LOOP
+#undef PGR_KSUM
+                        }
+                    }
+                    t = t_new; y0 = n0; y1 = n1; y2 = n2;
+                    f0 = k70; f1 = k71; f2 = k72;
+                    if ((t - t_bound) >= 0) status = PGR_RAY_OK;  // SCIPY/base.py:197
+                    else if (n_steps > a.max_steps) status = PGR_RAY_MAX_STEPS;
+                }
+            }
+        }
         const bool run = (status == RUNNING);
         const bool pend = run && (parked || need_init);
         const unsigned long long pm = __ballot(pend);
@@ -918,148 +1062,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                 }
             }
         }
-
-        if (status == RUNNING && !parked && !need_init) {
-            // ---- one attempt of RK45._step_impl, SCIPY/rk.py:111-176 ----
-            double min_step = min_step_of(t);
-            if (!rejected && h_abs < min_step) h_abs = min_step;  // clamp only on entry
-            bool too_small = h_abs < min_step;
-            double h = h_abs;
-            double t_new = t + h;
-            if ((t_new - t_bound) > 0) t_new = t_bound;
-            h = t_new - t;
-            h_abs = fabs(h);
-
-            // rk_step, SCIPY/rk.py:14-71 (K1 = f by FSAL)
-            double k20, k21, k22, k30, k31, k32, k40, k41, k42, k50, k51, k52, k60, k61, k62, k70,
-                k71, k72, cs;
-            double wr[5];
-            int ir[5];
-            C.step_weights(t, h, wr, ir);
-            C.rhs_w(wr[0], ir[0], y1 + (f1 * A21) * h, y2 + (f2 * A21) * h, k20, k21, k22, cs);
-            C.rhs_w(wr[1], ir[1], y1 + (f1 * A31 + k21 * A32) * h, y2 + (f2 * A31 + k22 * A32) * h, k30,
-                    k31, k32, cs);
-            C.rhs_w(wr[2], ir[2], y1 + (f1 * A41 + k21 * A42 + k31 * A43) * h,
-                    y2 + (f2 * A41 + k22 * A42 + k32 * A43) * h, k40, k41, k42, cs);
-            C.rhs_w(wr[3], ir[3], y1 + (f1 * A51 + k21 * A52 + k31 * A53 + k41 * A54) * h,
-                    y2 + (f2 * A51 + k22 * A52 + k32 * A53 + k42 * A54) * h, k50, k51, k52, cs);
-            C.rhs_w(wr[4], ir[4], y1 + (f1 * A61 + k21 * A62 + k31 * A63 + k41 * A64 + k51 * A65) * h,
-                    y2 + (f2 * A61 + k22 * A62 + k32 * A63 + k42 * A64 + k52 * A65) * h, k60, k61, k62,
-                    cs);
-            // y_new = y + h * (K[:-1].T @ B)   (B[1] = 0)
-            double n0 = y0 + h * (f0 * B1 + k30 * B3 + k40 * B4 + k50 * B5 + k60 * B6);
-            double n1 = y1 + h * (f1 * B1 + k31 * B3 + k41 * B4 + k51 * B5 + k61 * B6);
-            double n2 = y2 + h * (f2 * B1 + k32 * B3 + k42 * B4 + k52 * B5 + k62 * B6);
-            double c_new;
-            C.rhs_w(wr[4], ir[4], n1, n2, k70, k71, k72, c_new);  // f_new at t + h: the stage-6 abscissa
-            // error estimate, SCIPY/rk.py:106-110,146-147  (E[1] = 0)
-            double sc0 = atol + fmax(fabs(y0), fabs(n0)) * rtol;
-            double sc1 = atol + fmax(fabs(y1), fabs(n1)) * rtol;
-            double sc2 = atol + fmax(fabs(y2), fabs(n2)) * rtol;
-            double er0 = fdiv((f0 * E1 + k30 * E3 + k40 * E4 + k50 * E5 + k60 * E6 + k70 * E7) * h, sc0);
-            double er1 = fdiv((f1 * E1 + k31 * E3 + k41 * E4 + k51 * E5 + k61 * E6 + k71 * E7) * h, sc1);
-            double er2 = fdiv((f2 * E1 + k32 * E3 + k42 * E4 + k52 * E5 + k62 * E6 + k72 * E7) * h, sc2);
-            double error_norm = rms3(er0, er1, er2);
-
-            // ---- accept / reject and the next step size, SCIPY/rk.py:148-165, without branches: a
-            // taken skip-branch costs a lone in-order wave ~80 cycles (scripts/probes/branch_probe2),
-            // as much as 20 fp64 operations, and the slowest wave's latency is the fan's run time.
-            // ONE err^-0.2 serves both outcomes; where SciPy's min/max clamp decides (or the power
-            // is not finite: err = 0, NaN) the select takes the constant:
-            //   accept: min(MAX_FACTOR, SAFETY err^-0.2), the clamp is active below 0.09^5 = 5.9e-6
-            //   reject: max(MIN_FACTOR, SAFETY err^-0.2), the clamp is active above 4.5^5 = 1845, NaN
-            const bool accepted = !too_small && (error_norm < 1);
-            const bool reject = !too_small && !accepted;
-            const double pw = SAFETY * pow_m02(error_norm);
-            double fac_acc = (error_norm < 5.0e-6) ? MAX_FACTOR : ((pw < MAX_FACTOR) ? pw : MAX_FACTOR);
-            fac_acc = (rejected && !(fac_acc < 1)) ? 1.0 : fac_acc;
-            const double fac_rej = (error_norm < 1800.0) ? ((pw > MIN_FACTOR) ? pw : MIN_FACTOR) : MIN_FACTOR;
-            h_abs = too_small ? h_abs : h_abs * (accepted ? fac_acc : fac_rej);
-            rejected = too_small ? rejected : reject;
-            n_rej += reject ? 1 : 0;
-            const bool over = (int64_t)((unsigned)n_rej + (unsigned)n_steps) > attempt_limit;
-            status = too_small ? PGR_RAY_STEP_TOO_SMALL : ((reject & over) ? PGR_RAY_MAX_STEPS : status);
-
-            if (accepted) {
-                n_steps++;
-                // events at the new point, SCIPY/ivp.py:671-675 (c at (t_new, y_new) is the FSAL lookup)
-                unsigned g_new = C.events(t_new, n1, n2, c_new);
-                // find_active_events, SCIPY/ivp.py:133-156: values are +-1, so "up" = -1 -> +1,
-                // "down" = +1 -> -1; surface/bottom need "up", vertical/bbox take either
-                unsigned up = (~g) & g_new, down = g & (~g_new);
-                unsigned active = (up & 3u) | ((up | down) & 12u);
-                g = g_new;
-                bool want_samples = save && (jnext < S - 1) && (rnext <= t_new);
-                // samples behind the step (rnext < t: the extrapolated ones a segment's first step
-                // owns, Q5, |xi| up to 1e5) amplify rounding by xi^4 and keep SciPy's order
-                const bool scipy_order = exact_samples || (rnext < t);
-                Dense D;
-                if (active) {
-                    // park: the step is located, truncated and bounced in the next service phase
-                    PGR_FORM_Q();
-                    parked = true;
-                    pk_active = active;
-                    pk_tnew = t_new;
-                    pk_lds[0] = D.h;
-#pragma unroll
-                    for (int i = 0; i < 3; i++)
-#pragma unroll
-                        for (int j = 0; j < 4; j++) pk_lds[(1 + 4 * i + j) * blockDim.x] = D.q[i][j];
-                } else {
-                    // ---- _interpolate_ray, streamed (REF/launch_rays.py:763-772, Q5): samples of the
-                    // segment slice [idx1, idx2) that this step's quartic owns ----
-                    if (want_samples) {
-                        if (scipy_order) {
-                            PGR_FORM_Q();
-                            while (jnext < S - 1 && rnext <= t_new) {
-                                double o0, o1, o2;
-                                D.eval(t, y0, y1, y2, rnext, o0, o1, o2);
-                                Tp[(int64_t)jnext * a.stride_smp] = o0;
-                                Zp[(int64_t)jnext * a.stride_smp] = o1;
-                                Pp[(int64_t)jnext * a.stride_smp] = o2;
-                                jnext++;
-                                rnext = G.at(jnext);
-                            }
-                        } else {
-                            // The same quartic summed stage-major, y_old + h * sum_j K_j b_j(xi) with
-                            // b_j(xi) = sum_k P[j][k] xi^(k+1), in FMAs: no Q = K.T @ P to form (a third
-                            // of the work) and a few ulp from SciPy's summation order.  Output samples
-                            // never feed back into the integration, so this cannot move a ray.
-                            const double inv_h = frcp(h);
-#define PGR_KSUM(k1, k3, k4, k5, k6, k7)                                                          \
-    __builtin_fma(k1, b1, __builtin_fma(k3, b3, __builtin_fma(k4, b4, __builtin_fma(k5, b5,      \
-                  __builtin_fma(k6, b6, (k7) * b7)))))
-#define PGR_SAMPLE_LOOP(NEXT)                                                                     \
-    while (jnext < S - 1 && rnext <= t_new) {                                                     \
-        const double xi = (rnext - t) * inv_h, x2 = xi * xi;                                      \
-        const double b1 = xi * __builtin_fma(xi, __builtin_fma(xi, __builtin_fma(xi, P13, P12), P11), P10); \
-        const double b3 = x2 * __builtin_fma(xi, __builtin_fma(xi, P33, P32), P31);               \
-        const double b4 = x2 * __builtin_fma(xi, __builtin_fma(xi, P43, P42), P41);               \
-        const double b5 = x2 * __builtin_fma(xi, __builtin_fma(xi, P53, P52), P51);               \
-        const double b6 = x2 * __builtin_fma(xi, __builtin_fma(xi, P63, P62), P61);               \
-        const double b7 = x2 * __builtin_fma(xi, __builtin_fma(xi, P73, P72), P71);               \
-        Tp[(int64_t)jnext * a.stride_smp] = __builtin_fma(h, PGR_KSUM(f0, k30, k40, k50, k60, k70), y0); \
-        Zp[(int64_t)jnext * a.stride_smp] = __builtin_fma(h, PGR_KSUM(f1, k31, k41, k51, k61, k71), y1); \
-        Pp[(int64_t)jnext * a.stride_smp] = __builtin_fma(h, PGR_KSUM(f2, k32, k42, k52, k62, k72), y2); \
-        jnext++;                                                                                  \
-        rnext = NEXT;                                                                             \
-    }
-                            // two copies so that the linspace one holds no load: a load in the loop
-                            // makes every iteration wait (vmcnt) for the stores of the one before
-                            if (G.formula) { PGR_SAMPLE_LOOP(((jnext >= S - 1) ? G.x1 : grid_at(G.x0, G.step, jnext))) }
-                            else { PGR_SAMPLE_LOOP(G.r[jnext]) }
-#undef PGR_SAMPLE_LOOP
-#undef PGR_KSUM
-                        }
-                    }
-                    t = t_new; y0 = n0; y1 = n1; y2 = n2;
-                    f0 = k70; f1 = k71; f2 = k72;
-                    if ((t - t_bound) >= 0) status = PGR_RAY_OK;  // SCIPY/base.py:197
-                    else if (n_steps > a.max_steps) status = PGR_RAY_MAX_STEPS;
-                }
-            }
-        }
-    }
+    } while (__any(status == RUNNING));
 
     if (valid) {
         bool ok = (status == PGR_RAY_OK);
