@@ -60,6 +60,15 @@ extern "C" {
                                       instead of the default stage-major FMA form of the same quartic
                                       (a few ulp apart; samples never feed back into the integration) */
 
+#define PGR_STORED_SIGN 64u        /* T/z/p trajectories in pygenray's stored convention: z -> -z,
+                                      p -> -p (REF/ray_objects.py:51-52); end_state stays ODE-signed */
+
+#define PGR_COMPACT 128u           /* (host entry, with PGR_SAMPLE_MAJOR) dropped rays vanish from the
+                                      trajectories as they do from a pygenray RayFan
+                                      (REF/launch_rays.py:166-171): T/z/p come back as [S][M], M = number
+                                      of rays with status 0, in launch order, at the start of the caller's
+                                      [S][N] buffers; the per-ray arrays keep all N entries */
+
 typedef struct pgr_env pgr_env; /* opaque: environment tables resident in HBM */
 
 /* Number of visible HIP devices (<0 on error). */

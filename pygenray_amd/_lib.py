@@ -26,6 +26,8 @@ PGR_TERMINATE_BACKWARDS = 1
 PGR_SAMPLE_MAJOR = 2
 PGR_EXACT_BISECTION = 4
 PGR_EXACT_SAMPLES = 32
+PGR_STORED_SIGN = 64
+PGR_COMPACT = 128
 PGR_SAVE_LINSPACE = 8
 
 RAY_STATUS = {0: "ok", 1: "vertical", 2: "bbox", 3: "backward", 4: "step_too_small",
@@ -174,14 +176,15 @@ class EnvHandle:
     # ---- host-pointer entry (NumPy in / NumPy out) ----
     def shoot_fan(self, y0, source_range, receiver_range, num_range_save, rtol=1e-9, atol=1e-6,
                   terminate_backwards=True, max_steps=1_000_000, save=True, sample_major=False,
-                  exact_bisection=False, exact_samples=False):
+                  exact_bisection=False, exact_samples=False, stored_sign=False, compact=False):
         L = load()
         y0 = _c(y0).reshape(-1, 3)
         N, S = len(y0), int(num_range_save)
         r = np.linspace(source_range, receiver_range, S)
         flags = (PGR_TERMINATE_BACKWARDS if terminate_backwards else 0) | \
             (PGR_SAMPLE_MAJOR if sample_major else 0) | (PGR_EXACT_BISECTION if exact_bisection else 0) | \
-            (PGR_EXACT_SAMPLES if exact_samples else 0)
+            (PGR_EXACT_SAMPLES if exact_samples else 0) | (PGR_STORED_SIGN if stored_sign else 0) | \
+            (PGR_COMPACT if (compact and sample_major) else 0)
         if save:
             shape = (S, N) if sample_major else (N, S)
             T = np.empty(shape); Z = np.empty(shape); P = np.empty(shape)
@@ -194,6 +197,12 @@ class EnvHandle:
                               _vptr(r), S, float(rtol), float(atol), flags, int(max_steps),
                               _vptr(T), _vptr(Z), _vptr(P), _vptr(end), _vptr(nb), _vptr(ns),
                               _vptr(st), _vptr(nsteps), _vptr(nrej)))
+        if save and compact and sample_major:
+            # PGR_COMPACT: the trajectories of the M rays with status 0 sit as [S][M] at the start
+            # of the buffers
+            M = int(np.count_nonzero(st == 0))
+            if M < N:
+                T, Z, P = (a.reshape(-1)[:S * M].reshape(S, M) for a in (T, Z, P))
         return dict(r=r, T=T, z=Z, p=P, end=end, n_bott=nb, n_surf=ns, status=st, n_steps=nsteps,
                     n_rej=nrej)
 

@@ -28,6 +28,8 @@
 #include <string>
 #include <vector>
 #include <mutex>
+#include <thread>
+#include <initializer_list>
 
 #include "../../include/pgr.h"
 
@@ -679,6 +681,10 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     const bool save = (a.T != nullptr);
     const bool exact_samples = (a.flags & PGR_EXACT_SAMPLES) != 0;
     const int64_t attempt_limit = 4 * a.max_steps + 4096;  // guard against endless rejection
+    // PGR_STORED_SIGN: trajectories leave as pygenray stores them, z -> -z and p -> -p
+    // (REF/ray_objects.py:51-52): a sign-bit xor, exact, and two host passes over 1.6 GB less
+    const unsigned long long sgn = (a.flags & PGR_STORED_SIGN) ? 0x8000000000000000ULL : 0ULL;
+#define SGN(v) __longlong_as_double(__double_as_longlong(v) ^ (long long)sgn)
     SaveGrid G;
     G.r = a.r_save; G.x0 = a.x0; G.x1 = a.x1; G.step = a.save_step; G.inv_step = a.inv_dsave;
     G.S = S; G.formula = a.save_formula;
@@ -811,8 +817,8 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                                 double o0, o1, o2;
                                 D.eval(t, y0, y1, y2, rnext, o0, o1, o2);
                                 Tp[(int64_t)jnext * a.stride_smp] = o0;
-                                Zp[(int64_t)jnext * a.stride_smp] = o1;
-                                Pp[(int64_t)jnext * a.stride_smp] = o2;
+                                Zp[(int64_t)jnext * a.stride_smp] = SGN(o1);
+                                Pp[(int64_t)jnext * a.stride_smp] = SGN(o2);
                                 jnext++;
                                 rnext = G.at(jnext);
                             }
@@ -835,8 +841,8 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
         const double b6 = x2 * __builtin_fma(xi, __builtin_fma(xi, P63, P62), P61);               \
         const double b7 = x2 * __builtin_fma(xi, __builtin_fma(xi, P73, P72), P71);               \
         Tp[(int64_t)jnext * a.stride_smp] = __builtin_fma(h, PGR_KSUM(f0, k30, k40, k50, k60, k70), y0); \
-        Zp[(int64_t)jnext * a.stride_smp] = __builtin_fma(h, PGR_KSUM(f1, k31, k41, k51, k61, k71), y1); \
-        Pp[(int64_t)jnext * a.stride_smp] = __builtin_fma(h, PGR_KSUM(f2, k32, k42, k52, k62, k72), y2); \
+        Zp[(int64_t)jnext * a.stride_smp] = SGN(__builtin_fma(h, PGR_KSUM(f1, k31, k41, k51, k61, k71), y1)); \
+        Pp[(int64_t)jnext * a.stride_smp] = SGN(__builtin_fma(h, PGR_KSUM(f2, k32, k42, k52, k62, k72), y2)); \
         jnext++;                                                                                  \
         rnext = NEXT;                                                                             \
     }
@@ -966,8 +972,8 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                                 double o0, o1, o2;
                                 D.eval(t, y0, y1, y2, rnext, o0, o1, o2);
                                 Tp[(int64_t)jnext * a.stride_smp] = o0;
-                                Zp[(int64_t)jnext * a.stride_smp] = o1;
-                                Pp[(int64_t)jnext * a.stride_smp] = o2;
+                                Zp[(int64_t)jnext * a.stride_smp] = SGN(o1);
+                                Pp[(int64_t)jnext * a.stride_smp] = SGN(o2);
                                 jnext++;
                                 rnext = G.at(jnext);
                             }
@@ -1071,8 +1077,8 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
             if (ok) {
                 // last column = exact final state (REF/launch_rays.py:775-777)
                 Tp[(int64_t)(S - 1) * a.stride_smp] = y0;
-                Zp[(int64_t)(S - 1) * a.stride_smp] = y1;
-                Pp[(int64_t)(S - 1) * a.stride_smp] = y2;
+                Zp[(int64_t)(S - 1) * a.stride_smp] = SGN(y1);
+                Pp[(int64_t)(S - 1) * a.stride_smp] = SGN(y2);
             } else {
                 for (int j = 0; j < S; j++) {
                     Tp[(int64_t)j * a.stride_smp] = nan;
@@ -1628,6 +1634,43 @@ struct DevBuf {
 };
 }  // namespace
 
+// PGR_COMPACT: squeeze the columns of dropped rays out of a sample-major [S][N] array:
+// dst[s][m] = src[s][idx[m]], m < M (one pass at HBM speed; idx is increasing, so reads coalesce)
+__global__ void pgr_gather_cols(const double* __restrict__ src, double* __restrict__ dst,
+                                const int* __restrict__ idx, int64_t M, int64_t N)
+{
+    int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    int64_t s = blockIdx.y;
+    dst[s * M + m] = src[s * N + idx[m]];
+}
+
+// Touch (write) one byte of every page of the output buffers from up to 16 threads.  The buffers
+// are outputs that the following copies overwrite completely.
+static void prefault_outputs(std::initializer_list<double*> bufs, size_t bytes)
+{
+    const size_t page = 4096;
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt < 1 ? 1 : (nt > 16 ? 16 : nt);
+    std::vector<std::thread> th;
+    for (double* b : bufs) {
+        char* base = (char*)b;
+        size_t npages = (bytes + page - 1) / page;
+        size_t per = (npages + nt - 1) / nt;
+        for (unsigned k = 0; k < nt; k++) {
+            size_t p0 = (size_t)k * per, p1 = p0 + per < npages ? p0 + per : npages;
+            if (p0 >= p1) break;
+            th.emplace_back([base, bytes, p0, p1, page]() {
+                for (size_t q = p0; q < p1; q++) {
+                    size_t o = q * page;
+                    if (o < bytes) ((volatile char*)base)[o] = 0;
+                }
+            });
+        }
+    }
+    for (auto& t : th) t.join();
+}
+
 extern "C" int pgr_shoot_fan(pgr_env* env, const double* y0, int64_t N, double source_range,
                              double receiver_range, const double* r_save, int32_t S, double rtol,
                              double atol, uint32_t flags, int64_t max_steps, double* T, double* z,
@@ -1659,9 +1702,9 @@ extern "C" int pgr_shoot_fan(pgr_env* env, const double* y0, int64_t N, double s
         dZ{(char*)env->ws + off[3]}, dP{(char*)env->ws + off[4]}, dE{(char*)env->ws + off[5]},
         dnb{(char*)env->ws + off[6]}, dns{(char*)env->ws + off[7]}, dst{(char*)env->ws + off[8]},
         dn1{(char*)env->ws + off[9]}, dn2{(char*)env->ws + off[10]};
-    struct Trim {  // give a large workspace back when the call ends
+    struct Trim {  // give a very large workspace (> 16 GB of the 288 GB) back when the call ends
         pgr_env* e;
-        ~Trim() { if (e->ws_bytes > ((size_t)256 << 20)) { (void)hipFree(e->ws); e->ws = nullptr; e->ws_bytes = 0; } }
+        ~Trim() { if (e->ws_bytes > ((size_t)16 << 30)) { (void)hipFree(e->ws); e->ws = nullptr; e->ws_bytes = 0; } }
     } trim{env};
     HIPCHK(hipMemcpy(dy0.p, y0, N * 3 * sizeof(double), hipMemcpyHostToDevice));
     if (save) HIPCHK(hipMemcpy(dr.p, r_save, (size_t)S * sizeof(double), hipMemcpyHostToDevice));
@@ -1685,8 +1728,40 @@ extern "C" int pgr_shoot_fan(pgr_env* env, const double* y0, int64_t N, double s
                                   (int32_t*)dns.p, (int32_t*)dst.p, (int32_t*)dn1.p, (int32_t*)dn2.p,
                                   nullptr);
     if (rc) return rc;
+    // While the kernel runs: fault in the caller's (typically fresh, untouched) output buffers on
+    // several threads.  A D2H copy into untouched pageable memory runs at the page-fault rate of
+    // one thread (15 GB/s measured), into touched memory at 56 GB/s (scripts/probes/pcie_probe.py).
+    if (save && ns_bytes >= ((size_t)32 << 20)) prefault_outputs({T, z, p}, ns_bytes);
     HIPCHK(hipDeviceSynchronize());
-    if (save) {
+    HIPCHK(hipMemcpy(status, dst.p, N * 4, hipMemcpyDeviceToHost));
+    bool squeezed = false;
+    if (save && (flags & PGR_COMPACT)) {
+        if (!(flags & PGR_SAMPLE_MAJOR)) return fail("pgr_shoot_fan: PGR_COMPACT needs PGR_SAMPLE_MAJOR");
+        if (N > 0x7fffffff) return fail("pgr_shoot_fan: PGR_COMPACT supports at most 2^31 rays per call");
+        std::vector<int> keep;
+        keep.reserve((size_t)N);
+        for (int64_t k = 0; k < N; k++) if (status[k] == 0) keep.push_back((int)k);
+        const int64_t M = (int64_t)keep.size();
+        if (M < N) {
+            // dropped rays leave the trajectories on the device: [S][N] -> [S][M], then one linear copy
+            squeezed = true;
+            struct Buf { void* p = nullptr; ~Buf() { if (p) (void)hipFree(p); } } tmp, didx;
+            if (M > 0) {
+                HIPCHK(hipMalloc(&tmp.p, (size_t)S * (size_t)M * sizeof(double)));
+                HIPCHK(hipMalloc(&didx.p, (size_t)M * sizeof(int)));
+                HIPCHK(hipMemcpy(didx.p, keep.data(), (size_t)M * sizeof(int), hipMemcpyHostToDevice));
+                double* host[3] = {T, z, p};
+                void* dev[3] = {dT.p, dZ.p, dP.p};
+                for (int a3 = 0; a3 < 3; a3++) {
+                    hipLaunchKernelGGL(pgr_gather_cols, dim3((unsigned)((M + 255) / 256), (unsigned)S), dim3(256), 0,
+                                       nullptr, (const double*)dev[a3], (double*)tmp.p, (const int*)didx.p, M, N);
+                    HIPCHK(hipGetLastError());
+                    HIPCHK(hipMemcpy(host[a3], tmp.p, (size_t)S * (size_t)M * sizeof(double), hipMemcpyDeviceToHost));
+                }
+            }
+        }
+    }
+    if (save && !squeezed) {
         HIPCHK(hipMemcpy(T, dT.p, ns_bytes, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(z, dZ.p, ns_bytes, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(p, dP.p, ns_bytes, hipMemcpyDeviceToHost));
@@ -1694,7 +1769,6 @@ extern "C" int pgr_shoot_fan(pgr_env* env, const double* y0, int64_t N, double s
     if (end_state) HIPCHK(hipMemcpy(end_state, dE.p, N * 3 * sizeof(double), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(n_bott, dnb.p, N * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(n_surf, dns.p, N * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(status, dst.p, N * 4, hipMemcpyDeviceToHost));
     if (n_steps) HIPCHK(hipMemcpy(n_steps, dn1.p, N * 4, hipMemcpyDeviceToHost));
     if (n_rej) HIPCHK(hipMemcpy(n_rej, dn2.p, N * 4, hipMemcpyDeviceToHost));
     return 0;

@@ -47,7 +47,7 @@ def _device_env(environment, flatearth, backwards, device=0):
 
 def _shoot_ode_angles(source_depth, source_range, ode_angles_deg, receiver_range, num_range_save,
                       environment, rtol, terminate_backwards, flatearth, device=0, save=True,
-                      max_steps=1_000_000):
+                      max_steps=1_000_000, stored_sign=False, compact=False):
     """Batched _shoot_single_ray_process (REF/launch_rays.py:487-590): ODE-convention launch
     angles in, ODE-convention SoA out (in the mirrored frame for backwards shots)."""
     backwards = receiver_range < source_range
@@ -69,7 +69,7 @@ def _shoot_ode_angles(source_depth, source_range, ode_angles_deg, receiver_range
     # write traffic) and are handed on as transposed (N, S) views -- same indexing as pygenray
     out = env.shoot_fan(y0, source_range_i, receiver_range_i, num_range_save, rtol=rtol,
                         terminate_backwards=terminate_backwards, save=save, max_steps=max_steps,
-                        sample_major=True)
+                        sample_major=True, stored_sign=stored_sign, compact=compact)
     if save:
         out["T"], out["z"], out["p"] = out["T"].T, out["z"].T, out["p"].T
     if backwards:
@@ -102,19 +102,16 @@ def shoot_rays(source_depth, source_range, launch_angles, receiver_range, num_ra
     else:
         ode = launch_angles
         stored = -launch_angles  # REF/launch_rays.py:180
+    # stored convention z -> -z, p -> -p (REF/ray_objects.py:51-52) applied by the kernel's stores
     out = _shoot_ode_angles(source_depth, source_range, ode, receiver_range, num_range_save,
-                            environment, rtol, terminate_backwards, flatearth, device=device)
+                            environment, rtol, terminate_backwards, flatearth, device=device,
+                            stored_sign=True, compact=True)
     _report_drops(out["status"], debug)
     keep = out["status"] == 0
     S = len(out["r"])
     M = int(keep.sum())
     rs = np.tile(out["r"], (M, 1)) if M * S <= 20_000_000 else np.broadcast_to(out["r"], (M, S))
-    if keep.all():
-        T, Z, P = out["T"], out["z"], out["p"]
-    else:
-        T, Z, P = out["T"][keep], out["z"][keep], out["p"][keep]
-    np.negative(Z, out=Z)  # stored convention z -> -z, p -> -p (REF/ray_objects.py:51-52)
-    np.negative(P, out=P)
+    T, Z, P = out["T"], out["z"], out["p"]  # (M, S) views: dropped rays were squeezed out on the device
     return RayFan.from_arrays(stored[keep], rs, T, Z, P, out["n_bott"][keep].astype(np.int64),
                               out["n_surf"][keep].astype(np.int64), np.full(M, source_depth))
 

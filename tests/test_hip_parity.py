@@ -251,6 +251,26 @@ def test_layouts_and_end_state_only(lib):
         lib.EnvHandle(arrs[0], arrs[1], arrs[2], arrs[3], arrs[4][:3], arrs[5][:3], arrs[6][:3])
 
 
+def test_compact_and_stored_sign_flags(lib):
+    """PGR_COMPACT squeezes dropped rays out of the [S][N] trajectories on the device and
+    PGR_STORED_SIGN stores -z, -p: both are exactly the host-side post-processing they replace."""
+    arrs = munk_arrays(100e3)
+    th = np.concatenate([np.linspace(-19, 19, 150), [89.9995, -89.9995, 89.9999], np.linspace(-5, 5, 20)])
+    y0 = y0_for(oracle, arrs, 1000.0, 0.0, th)
+    env = lib.EnvHandle(*arrs)
+    a = env.shoot_fan(y0, 0.0, 100e3, 33, sample_major=True)
+    b = env.shoot_fan(y0, 0.0, 100e3, 33, sample_major=True, compact=True, stored_sign=True)
+    keep = a["status"] == 0
+    assert 0 < keep.sum() < len(th)                     # some rays really are dropped
+    assert np.array_equal(a["status"], b["status"]) and np.array_equal(a["end"], b["end"], equal_nan=True)
+    assert b["T"].shape == (33, int(keep.sum()))
+    assert np.array_equal(b["T"], a["T"][:, keep])
+    assert np.array_equal(b["z"], -a["z"][:, keep]) and np.array_equal(b["p"], -a["p"][:, keep])
+    # nothing dropped -> same layout as without the flag
+    c = env.shoot_fan(y0[:150], 0.0, 100e3, 33, sample_major=True, compact=True)
+    assert c["T"].shape == (33, 150) and np.array_equal(c["z"], a["z"][:, :150])
+
+
 def test_sample_evaluation_orders_agree(lib):
     """Default (stage-major FMA) and PGR_EXACT_SAMPLES (SciPy's Q = K.T @ P order) evaluate
     the SAME quartics of the SAME integration: steps, end states and the exact last column are
