@@ -45,6 +45,24 @@ def cases():
     # (e) LDS table variant with a fine range grid (range independent, 100 m cells)
     arrs4 = munk_arrays(100e3, nr=1001)
     out["munk_fine_r"] = (arrs4, fan_y0(arrs4, 1000.0, 0.0, -np.linspace(-20, 20, 1000)), 0.0, 100e3, 40, dict(rtol=1e-6))
+    # (f) the reference's default: flat-earth transformed tables (smoothly non-uniform zin), range
+    # independent (LDS table) and range dependent (HBM table)
+    import pygenray_amd as pr
+    from pygenray_amd.environment import _unpack_envi
+    zz = np.arange(0, 6000, 1.0); rr = np.linspace(0, 500e3, 51)
+    for name, slope in (("flatearth_indep", 0.0), ("flatearth_rangedep", 2e-4)):
+        c2 = np.array([pr.munk_ssp(zz, 1300 + slope * ri) for ri in rr])
+        env = pr.OceanEnvironment2D(pr.DataArray(c2, dims=["range", "depth"], coords={"range": rr, "depth": zz}),
+                                    pr.DataArray(np.full(51, 5000.0), dims=["range"], coords={"range": rr}),
+                                    flat_earth_transform=True)
+        arrs5 = _unpack_envi(env, flatearth=True)
+        out[name] = (arrs5, fan_y0(arrs5, 1000.0, 0.0, -np.linspace(-20, 20, 2000)), 0.0, 500e3, 51, {})
+    # (g) strongly non-uniform depth grid (fine near the surface, coarse at depth), range independent
+    zg = np.concatenate([np.linspace(0, 200, 401), np.linspace(200, 5500, 531)[1:]])
+    cg = np.tile(1500 * (1 + 0.00737 * ((2 * (zg - 1300) / 1300) - 1 + np.exp(-(2 * (zg - 1300) / 1300)))), (30, 1))
+    rg = np.linspace(0, 300e3, 30)
+    arrs6 = (cg, np.gradient(cg, zg, axis=1), rg, zg, np.full(30, 5200.0), rg.copy(), np.zeros(30))
+    out["nonuniform_indep"] = (arrs6, fan_y0(arrs6, 300.0, 0.0, -np.linspace(-15, 15, 1000)), 0.0, 300e3, 40, {})
     return out
 
 
