@@ -105,6 +105,8 @@ def load():
     L.pgr_shoot_fan.argtypes = fan_common
     L.pgr_shoot_fan_device.restype = ctypes.c_int
     L.pgr_shoot_fan_device.argtypes = fan_common + [_vp]
+    L.pgr_set_depth_search.restype = ctypes.c_int
+    L.pgr_set_depth_search.argtypes = [ctypes.c_int]
     L.pgr_set_waves_per_block.restype = ctypes.c_int
     L.pgr_set_waves_per_block.argtypes = [ctypes.c_int]
     L.pgr_set_park.restype = ctypes.c_int
@@ -237,6 +239,11 @@ def debug_math(a, b):
 
 def device_count():
     return load().pgr_device_count()
+
+
+def set_depth_search(mode):
+    """0: automatic (bucketed search for non-uniform zin when it fits the LDS), 1: binary search."""
+    check(load().pgr_set_depth_search(int(mode)))
 
 
 def set_waves_per_block(w):

@@ -54,6 +54,12 @@ struct EnvDev {
     double r0, dr, inv_dr;
     double b0, db, inv_db;
     double zlo_tol, zhi_tol, rlo_tol, rhi_tol;  // bbox bounds -+ 1e-6 (REF/integration_processes.py:295-302)
+    // bucketed depth search for non-uniform zin (e.g. the flat-earth transformed grid): zbucket[k]
+    // = the cell index at the lower edge of uniform bin k of width zb_w <= 0.9 min(diff(zin)), so
+    // the cell of any z in bin k is zbucket[k] or zbucket[k] + 1 (host verified)
+    const unsigned short* zbucket;
+    int z_bucket, zb_B;
+    double zb_z0, zb_inv_w;
 };
 
 struct FanArgs {
@@ -76,6 +82,7 @@ struct FanArgs {
     double save_step;  // linspace step when save_formula
     int save_formula;  // r_save[j] == j*save_step + x0 bitwise (host verified)
     int park_lanes, park_trips;  // service batching thresholds
+    double* park_ws;      // [13][gridDim.x * blockDim.x] parked dense outputs when the LDS is full (ZM == 2)
     const int* wave_map;  // [gridDim.x * waves_per_block] global wave of each slot, -1 = empty; null = strided deal
     int64_t max_steps;
     uint32_t flags;
@@ -296,10 +303,19 @@ __device__ __forceinline__ int cell_search(double q, const double* __restrict__ 
 // ZS ("z simple"): zin[j] == j*dz bitwise with dz a power of two and zin[0] == 0 (e.g. the
 // reference's default np.arange(0, 6000, 1)): the cell index is ceil(z/dz) - 1 and the weight an
 // exact scaling -- no search, no fix-up, no division.
-template <bool LDS_TAB, bool ZS>
+// ZM = 2 ("z bucketed"): any other increasing zin whose bucket table fits the LDS: one LDS read
+// gives the candidate cell, the next three nodes of zin (and of the profile) are read together
+// and a compare picks the cell -- two dependent LDS reads instead of a 13-step binary search
+// through L2 (the reference's default flat-earth grid: 36 -> 11 ms per 1e5-ray fan).
+template <bool LDS_TAB, int ZM>
 struct Ctx {
+    static constexpr bool ZS = (ZM == 1);
     const EnvDev& e;
     const double2* lds;  // LDS copy of the (single) depth profile when LDS_TAB
+    const double* lds_z;            // ZM == 2: LDS copy of zin
+    const unsigned short* lds_zb;   // ZM == 2: LDS copy of zbucket
+    const double h_zb_z0, h_zb_inv_w;
+    const int h_zb_B;
     // per-lane caches: x only moves forward, so the range cell (and the bathymetry cell under
     // the ray) changes once every ~10 km; keep its edges and the reciprocal of its width
     mutable double r_lo, r_hi, r_yden, r_hi2;  // r_hi2: upper edge of the NEXT cell (uniform rin) or r_hi
@@ -309,8 +325,10 @@ struct Ctx {
     const double h_inv_dz, h_dz, h_r0, h_dr, h_inv_dr;
     const double* const h_rin;
     const int h_nz, h_nr, h_r_uniform;
-    __device__ __forceinline__ Ctx(const EnvDev& e_, const double2* l)
-        : e(e_), lds(l), h_inv_dz(e_.inv_dz), h_dz(e_.dz), h_r0(e_.r0), h_dr(e_.dr),
+    __device__ __forceinline__ Ctx(const EnvDev& e_, const double2* l, const double* lz = nullptr,
+                                   const unsigned short* lzb = nullptr)
+        : e(e_), lds(l), lds_z(lz), lds_zb(lzb), h_zb_z0(e_.zb_z0), h_zb_inv_w(e_.zb_inv_w),
+          h_zb_B(e_.zb_B), h_inv_dz(e_.inv_dz), h_dz(e_.dz), h_r0(e_.r0), h_dr(e_.dr),
           h_inv_dr(e_.inv_dr), h_rin(e_.rin), h_nz(e_.nz), h_nr(e_.nr), h_r_uniform(e_.r_uniform)
     {
         r_lo = 1.0; r_hi = 0.0; r_yden = 1.0; r_hi2 = 0.0; r_i = 0;  // empty interval: first use refills
@@ -376,7 +394,25 @@ struct Ctx {
     {
         int j;
         double wy;
-        if (ZS) {
+        double2 pre00 = {0, 0}, pre01 = {0, 0};  // ZM == 2 with the LDS table: nodes already fetched
+        if (ZM == 2) {
+            // bin -> candidate cell j0 (zin[j0] < every z of the bin <= zin[j0 + 2]); the three
+            // nodes from j0 on are fetched together, then z > zin[j0 + 1] picks the upper cell
+            const double t = (z - h_zb_z0) * h_zb_inv_w;
+            const int k = min(max((int)floor(t), 0), h_zb_B - 1);  // NaN -> 0, like cell_search
+            const int j0 = lds_zb[k];
+            const int j2 = min(j0 + 2, h_nz - 1);
+            const double za = lds_z[j0], zb = lds_z[j0 + 1], zc = lds_z[j2];
+            const bool up = (z > zb) & (j0 + 1 <= h_nz - 2);
+            j = j0 + (up ? 1 : 0);
+            const double zj = up ? zb : za, zj1 = up ? zc : zb;
+            wy = fdiv(z - zj, zj1 - zj);
+            if (LDS_TAB) {
+                const double2 t0 = lds[j0], t1 = lds[j0 + 1], t2 = lds[j2];
+                pre00 = up ? t1 : t0;
+                pre01 = up ? t2 : t1;
+            }
+        } else if (ZS) {
             double t = z * h_inv_dz;                     // exact
             // v_cvt_i32_f64 saturates and maps NaN to 0: no clamp needed before the conversion
             j = min(max((int)ceil(t) - 1, 0), h_nz - 2);
@@ -389,8 +425,8 @@ struct Ctx {
         }
         double2 v00, v01, v10, v11;
         if (LDS_TAB) {
-            v00 = lds[j];
-            v01 = lds[j + 1];
+            if (ZM == 2) { v00 = pre00; v01 = pre01; }
+            else { v00 = lds[j]; v01 = lds[j + 1]; }
             v10 = v00;  // range independent: rows are bitwise identical
             v11 = v01;
         } else {
@@ -644,7 +680,7 @@ struct SaveGrid {
 // lanes together (when `park_lanes` lanes wait, or the oldest has waited `park_trips` trips, or
 // nobody else can step).  Per-ray arithmetic is unchanged by when the service runs.
 // ------------------------------------------------------------------------------------
-template <bool LDS_TAB, bool ZS>
+template <bool LDS_TAB, int ZM>
 __global__ void __launch_bounds__(512)
 pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
 {
@@ -653,12 +689,21 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     // literals) into constant re-materialisation + SGPR spills inside the step loop
     const EnvDev& env = *env_p;
     extern __shared__ double2 lds_tab[];
+    // LDS layout: [{c, cp}[nz] when LDS_TAB][zin[nz], zbucket[zb_B] when ZM == 2][parked dense
+    // outputs, 13 doubles per lane, when ZM != 2]
+    double* const lds_after_tab = (double*)(lds_tab + (LDS_TAB ? env.nz : 0));
+    double* const lds_z = lds_after_tab;
+    unsigned short* const lds_zb = (unsigned short*)(lds_z + env.nz);
     if (LDS_TAB) {
         // stage the single depth profile {c, cp}[nz] into LDS (coalesced 16 B per lane)
         for (int j = threadIdx.x; j < env.nz; j += blockDim.x) lds_tab[j] = env.tab[j];
-        __syncthreads();
     }
-    const Ctx<LDS_TAB, ZS> C(env, lds_tab);
+    if (ZM == 2) {
+        for (int j = threadIdx.x; j < env.nz; j += blockDim.x) lds_z[j] = env.zin[j];
+        for (int j = threadIdx.x; j < env.zb_B; j += blockDim.x) lds_zb[j] = env.zbucket[j];
+    }
+    if (LDS_TAB || ZM == 2) __syncthreads();
+    const Ctx<LDS_TAB, ZM> C(env, lds_tab, lds_z, lds_zb);
     // waves are dealt to workgroups round-robin (wave w of block b = global wave w*grid + b):
     // neighbouring launch angles cost alike, so a strided deal balances the CUs
     int64_t gwave = (int64_t)(threadIdx.x >> 6) * gridDim.x + blockIdx.x;
@@ -705,7 +750,11 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     // A parked lane keeps the dense output of the step it is holding in LDS, 13 doubles per lane
     // laid out [13][blockDim.x] behind the table (t_old = t, y_old = y stay live in registers):
     // written once per boundary hit, read once per service, and 26 VGPRs less loop-carried state.
-    double* const pk_lds = (double*)(lds_tab + (LDS_TAB ? env.nz : 0)) + threadIdx.x;
+    // (ZM == 2: zin and its bucket table take that LDS; the parked outputs go to a global
+    // workspace instead -- a boundary hit is rare enough for an L2 round trip)
+    const int pk_stride = (ZM == 2) ? (int)(gridDim.x * blockDim.x) : (int)blockDim.x;
+    double* const pk_lds = (ZM == 2) ? (a.park_ws + (size_t)blockIdx.x * blockDim.x + threadIdx.x)
+                                     : (lds_after_tab + threadIdx.x);
     double pk_tnew = 0;
     unsigned pk_active = 0;
     int waited = 0;
@@ -806,7 +855,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
 #pragma unroll
                     for (int i = 0; i < 3; i++)
 #pragma unroll
-                        for (int j = 0; j < 4; j++) pk_lds[(1 + 4 * i + j) * blockDim.x] = D.q[i][j];
+                        for (int j = 0; j < 4; j++) pk_lds[(size_t)(1 + 4 * i + j) * pk_stride] = D.q[i][j];
                 } else {
                     // ---- _interpolate_ray, streamed (REF/launch_rays.py:763-772, Q5): samples of the
                     // segment slice [idx1, idx2) that this step's quartic owns ----
@@ -879,7 +928,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
 #pragma unroll
                     for (int i = 0; i < 3; i++)
 #pragma unroll
-                        for (int j = 0; j < 4; j++) D.q[i][j] = pk_lds[(1 + 4 * i + j) * blockDim.x];
+                        for (int j = 0; j < 4; j++) D.q[i][j] = pk_lds[(size_t)(1 + 4 * i + j) * pk_stride];
                     const double t_new = pk_tnew, h = D.h;
                     int ev = -1;
                     double best = 0;
@@ -1194,7 +1243,7 @@ __global__ void pgr_eval_kernel(EnvDev env, const double* x, const double* y, in
 {
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= M) return;
-    const Ctx<false, false> C(env, nullptr);
+    const Ctx<false, 0> C(env, nullptr);
     double d0, d1, d2, c;
     C.rhs(x[k], y[3 * k + 1], y[3 * k + 2], d0, d1, d2, c);
     double* o = out + 10 * k;
@@ -1244,6 +1293,7 @@ __global__ void pgr_math_kernel(const double* a, const double* b, int64_t M, dou
 // ====================================================================================
 static thread_local std::string g_err;
 static int g_waves_per_block = 0;
+static int g_depth_search = 0;  // 0: automatic, 1: never use the bucketed search (tests)
 static const size_t PARK_BYTES = 13 * sizeof(double);  // h + Q[3][4] of a parked lane (LDS)
 static int g_park_lanes = 64, g_park_trips = 16;
 static int g_place = 2;  // 0 off, 1 issue priorities only, 2 cost-aware placement + priorities
@@ -1275,6 +1325,11 @@ struct pgr_env {
     size_t place_slot_bytes = 0;
     int place_next = 0;
     std::mutex place_mutex;
+    // ring of global workspaces for the parked dense outputs of bucketed-z launches
+    static constexpr int kParkRing = 4;
+    void* park_buf = nullptr;      // owned through `allocs`
+    size_t park_slot_bytes = 0;
+    int park_next = 0;
     int range_indep = 0;
     int lds_path = 0;
     std::vector<void*> allocs;
@@ -1303,6 +1358,13 @@ extern "C" int pgr_set_placement(int mode)
 {
     if (mode < 0 || mode > 2) return fail("pgr_set_placement: 0 = off, 1 = priorities only, 2 = placement + priorities");
     g_place = mode;
+    return 0;
+}
+
+extern "C" int pgr_set_depth_search(int mode)
+{
+    if (mode < 0 || mode > 1) return fail("pgr_set_depth_search: 0 = automatic, 1 = no bucket table");
+    g_depth_search = mode;
     return 0;
 }
 
@@ -1480,6 +1542,31 @@ extern "C" int pgr_env_create(pgr_env** out, int device, const double* cin, cons
     d.zlo_tol = zin[0] - tol;
     d.rlo_tol = rin[0] - tol;
     d.rhi_tol = rin[nr - 1] + tol;
+    // bucketed depth search for a non-uniform zin (see EnvDev): bins of 0.9 min(diff(zin))
+    d.z_bucket = 0; d.zbucket = nullptr; d.zb_B = 0; d.zb_z0 = 0.0; d.zb_inv_w = 0.0;
+    if (!d.z_uniform && nz >= 3 && nz <= 65535) {
+        double min_dz = zin[1] - zin[0];
+        for (int64_t j = 1; j + 1 < nz; j++) min_dz = (zin[j + 1] - zin[j] < min_dz) ? zin[j + 1] - zin[j] : min_dz;
+        const double span = zin[nz - 1] - zin[0];
+        const double w = 0.9 * min_dz;
+        if (min_dz > 0 && span > 0 && std::floor(span / w) + 2 <= 32768.0) {
+            const int B = (int)(std::floor(span / w) + 2);
+            std::vector<unsigned short> bk((size_t)B);
+            bool ok = true;
+            int64_t j = 0;
+            for (int k = 0; k < B && ok; k++) {
+                // every z the device maps to bin k (floor((z - z0) * (1/w)), two roundings) lies in [L, U)
+                const double L = zin[0] + w * ((double)k - (double)(k + 1) * 1e-12);
+                const double U = zin[0] + w * ((double)(k + 1) + (double)(k + 1) * 1e-12);
+                while (j + 1 <= nz - 2 && zin[j + 1] < L) j++;  // j = max{ j : zin[j] < L } in [0, nz-2]
+                bk[(size_t)k] = (unsigned short)j;
+                if (j + 2 <= nz - 1 && !(U <= zin[j + 2])) ok = false;  // the cell is j or j+1, never beyond
+            }
+            if (ok && upload(e, bk.data(), bk.size(), &d.zbucket) == 0) {
+                d.z_bucket = 1; d.zb_B = B; d.zb_z0 = zin[0]; d.zb_inv_w = 1.0 / w;
+            }
+        }
+    }
     if (upload(e, &e->d, 1, &e->d_dev)) { pgr_env_destroy(e); return -1; }
     *out = e;
     return 0;
@@ -1577,36 +1664,43 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
 
     int64_t waves = (N + 63) / 64;
     hipStream_t st = (hipStream_t)stream;
-    if (env->lds_path) {
+    // kernel variant: where the table lives (LDS copy of the single profile / HBM) and how a depth
+    // cell is found (1: zin[j] = j dz exactly, 2: bucket table + zin in LDS, 0: closed form for other
+    // uniform grids or binary search)
+    const EnvDev& D = env->d;
+    const size_t tab_bytes = (size_t)D.nz * sizeof(double2);
+    const size_t zb_bytes = D.z_bucket ? ((size_t)D.nz * sizeof(double) + (((size_t)D.zb_B * 2 + 15) & ~(size_t)15)) : 0;
+    bool lds_tab = env->lds_path != 0;
+    int zm = D.z_simple ? 1 : 0;
+    if (!D.z_simple && D.z_bucket && g_depth_search == 0) {
+        if (env->range_indep && tab_bytes + zb_bytes <= env->max_lds) { lds_tab = true; zm = 2; }
+        else if (zb_bytes <= env->max_lds) { lds_tab = false; zm = 2; }
+    }
+    int wpb, threads;
+    int64_t blocks;
+    size_t lds;
+    if (lds_tab) {
         // one workgroup per CU (the LDS table is per workgroup): the smallest workgroup that
-        // covers the fan in a single round, capped at 16 waves
-        int wpb = g_waves_per_block;
+        // covers the fan in a single round, capped at 8 waves
+        wpb = g_waves_per_block;
         if (wpb == 0) {
             wpb = (int)((waves + env->num_cus - 1) / env->num_cus);
             if (wpb < 1) wpb = 1;
             if (wpb > 8) wpb = 8;
         }
-        // the table shares the LDS with the parked lanes' dense outputs (PARK_BYTES per lane)
-        const size_t tab_bytes = (size_t)env->d.nz * sizeof(double2);
-        const int wpb_fit = (int)((env->max_lds - tab_bytes) / (PARK_BYTES * 64));
-        if (wpb > wpb_fit) wpb = wpb_fit;
-        int threads = wpb * 64;
-        int64_t blocks = (N + threads - 1) / threads;
+        if (zm != 2) {
+            // the table shares the LDS with the parked lanes' dense outputs (PARK_BYTES per lane)
+            const int wpb_fit = (int)((env->max_lds - tab_bytes) / (PARK_BYTES * 64));
+            if (wpb > wpb_fit) wpb = wpb_fit;
+        }
+        threads = wpb * 64;
+        blocks = (N + threads - 1) / threads;
         // cost-aware scheduling of the waves (placement, priorities, homogeneous workgroups)
         if (schedule_waves(env, y0, N, waves, wpb, st, a.wave_map, blocks)) return -1;
-        size_t lds = tab_bytes + PARK_BYTES * (size_t)threads;
-        if (env->d.z_simple) {
-            HIPCHK(hipFuncSetAttribute((const void*)pgr_fan_kernel<true, true>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((pgr_fan_kernel<true, true>), dim3((unsigned)blocks), dim3(threads), lds, st, env->d_dev, a);
-        } else {
-            HIPCHK(hipFuncSetAttribute((const void*)pgr_fan_kernel<true, false>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((pgr_fan_kernel<true, false>), dim3((unsigned)blocks), dim3(threads), lds, st, env->d_dev, a);
-        }
+        lds = tab_bytes + (zm == 2 ? zb_bytes : PARK_BYTES * (size_t)threads);
     } else {
-        int wpb = g_waves_per_block ? g_waves_per_block : 4;
-        int64_t blocks = (waves + wpb - 1) / wpb;
+        wpb = g_waves_per_block ? g_waves_per_block : 4;
+        blocks = (waves + wpb - 1) / wpb;
         // the same scheduling; a fan too small for it keeps 4-wave workgroups
         if (waves > 4 * (int64_t)env->num_cus) {
             int W = waves <= 8 * (int64_t)env->num_cus ? (int)((waves + env->num_cus - 1) / env->num_cus) : 8;
@@ -1615,13 +1709,37 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
             if (schedule_waves(env, y0, N, waves, W, st, m, nb2)) return -1;
             if (m) { a.wave_map = m; blocks = nb2; wpb = W; }
         }
-        int threads = wpb * 64;
-        size_t lds = PARK_BYTES * (size_t)threads;
-        if (env->d.z_simple)
-            hipLaunchKernelGGL((pgr_fan_kernel<false, true>), dim3((unsigned)blocks), dim3(threads), lds, st, env->d_dev, a);
-        else
-            hipLaunchKernelGGL((pgr_fan_kernel<false, false>), dim3((unsigned)blocks), dim3(threads), lds, st, env->d_dev, a);
+        threads = wpb * 64;
+        lds = (zm == 2) ? zb_bytes : PARK_BYTES * (size_t)threads;
     }
+    if (zm == 2) {
+        // parked dense outputs in global memory: [13][blocks * threads] doubles from a small ring
+        // (launches of one env on different streams must not share a slot)
+        std::lock_guard<std::mutex> lock(env->place_mutex);
+        size_t need = (PARK_BYTES * (size_t)blocks * (size_t)threads + 255) & ~(size_t)255;
+        if (need > env->park_slot_bytes) {
+            void* nb = nullptr;
+            HIPCHK(hipMalloc(&nb, need * pgr_env::kParkRing));
+            env->allocs.push_back(nb);
+            env->park_buf = nb;
+            env->park_slot_bytes = need;
+        }
+        a.park_ws = (double*)((char*)env->park_buf + (size_t)(env->park_next++ % pgr_env::kParkRing) * env->park_slot_bytes);
+    }
+#define PGR_LAUNCH(LT, ZMV)                                                                          \
+    do {                                                                                             \
+        if (lds > 64 * 1024)                                                                         \
+            HIPCHK(hipFuncSetAttribute((const void*)pgr_fan_kernel<LT, ZMV>,                         \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));       \
+        hipLaunchKernelGGL((pgr_fan_kernel<LT, ZMV>), dim3((unsigned)blocks), dim3(threads), lds, st, \
+                           env->d_dev, a);                                                           \
+    } while (0)
+    if (lds_tab) {
+        if (zm == 1) PGR_LAUNCH(true, 1); else if (zm == 2) PGR_LAUNCH(true, 2); else PGR_LAUNCH(true, 0);
+    } else {
+        if (zm == 1) PGR_LAUNCH(false, 1); else if (zm == 2) PGR_LAUNCH(false, 2); else PGR_LAUNCH(false, 0);
+    }
+#undef PGR_LAUNCH
     HIPCHK(hipGetLastError());
     return 0;
 }

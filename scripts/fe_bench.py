@@ -11,7 +11,8 @@ from pygenray_amd.device_fan import DeviceFan, fan_y0
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 rmax = 1000e3
 z = np.arange(0, 6000, 1.0); r = np.linspace(0, rmax, 100)
-ssp = pr.DataArray(np.tile(pr.munk_ssp(z), (100, 1)), dims=["range", "depth"], coords={"range": r, "depth": z})
+slope = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0   # > 0: range-dependent sound speed (table stays in HBM)
+ssp = pr.DataArray(np.array([pr.munk_ssp(z, 1300 + slope * ri) for ri in r]), dims=["range", "depth"], coords={"range": r, "depth": z})
 bathy = pr.DataArray(np.full(100, 5000.0), dims=["range"], coords={"range": r})
 env = pr.OceanEnvironment2D(ssp, bathy, flat_earth_transform=True)
 for fe in (False, True):

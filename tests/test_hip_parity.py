@@ -251,6 +251,44 @@ def test_layouts_and_end_state_only(lib):
         lib.EnvHandle(arrs[0], arrs[1], arrs[2], arrs[3], arrs[4][:3], arrs[5][:3], arrs[6][:3])
 
 
+def test_bucketed_depth_search_equals_binary_search(lib):
+    """Non-uniform zin (the reference's default flat-earth grid, and a strongly graded one): the
+    bucket-table cell search in LDS returns the cells of np.searchsorted -- every output bit equals
+    the binary-search build of the same kernel, for the LDS-table and the HBM-table variant."""
+    import pygenray_amd as pr
+    from pygenray_amd.environment import _unpack_envi
+    zz = np.arange(0, 6000, 1.0)
+    rr = np.linspace(0, 200e3, 21)
+    cases = []
+    for slope in (0.0, 2e-4):   # range independent / dependent
+        c2 = np.array([pr.munk_ssp(zz, 1300 + slope * ri) for ri in rr])
+        env = pr.OceanEnvironment2D(pr.DataArray(c2, dims=["range", "depth"], coords={"range": rr, "depth": zz}),
+                                    pr.DataArray(np.full(21, 5000.0), dims=["range"], coords={"range": rr}),
+                                    flat_earth_transform=True)
+        cases.append(_unpack_envi(env, flatearth=True))
+    zg = np.concatenate([np.linspace(0, 300, 301), np.linspace(300, 5500, 261)[1:]])   # 1 m and 20 m cells
+    cg = np.tile(munk(zg), (21, 1))
+    cases.append((cg, np.gradient(cg, zg, axis=1), rr, zg, np.full(21, 5200.0), rr.copy(), np.zeros(21)))
+    for arrs in cases:
+        assert not np.allclose(np.diff(arrs[3]), np.diff(arrs[3])[0], rtol=1e-12, atol=0)  # really non-uniform
+        y0 = y0_for(oracle, arrs, 400.0, 0.0, np.linspace(-19, 19, 500))
+        env = lib.EnvHandle(*arrs)
+        try:
+            a = env.shoot_fan(y0, 0.0, 200e3, 41)
+            lib.set_depth_search(1)
+            b = env.shoot_fan(y0, 0.0, 200e3, 41)
+        finally:
+            lib.set_depth_search(0)
+        for k in ("T", "z", "p", "end"):
+            assert np.array_equal(a[k], b[k], equal_nan=True), k
+        for k in ("status", "n_steps", "n_rej", "n_bott", "n_surf"):
+            assert np.array_equal(a[k], b[k]), k
+        # and a depth below / above the grid still clamps to the edge cells (Q4)
+        pts = env.eval_points(np.array([10e3, 10e3]), np.array([[0, arrs[3][0] - 5.0, 0], [0, arrs[3][-1] + 5.0, 0]]))
+        assert np.all(np.isfinite(pts[:, 3]))
+        env.close()
+
+
 def test_compact_and_stored_sign_flags(lib):
     """PGR_COMPACT squeezes dropped rays out of the [S][N] trajectories on the device and
     PGR_STORED_SIGN stores -z, -p: both are exactly the host-side post-processing they replace."""
