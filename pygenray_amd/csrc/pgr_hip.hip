@@ -82,6 +82,7 @@ struct FanArgs {
     double save_step;  // linspace step when save_formula
     int save_formula;  // r_save[j] == j*save_step + x0 bitwise (host verified)
     int park_lanes, park_trips;  // service batching thresholds
+    int bathy_lds_off;    // byte offset of the LDS copy of {depth_ranges[nb], depths[nb]}, or -1 (read from HBM)
     double* park_ws;      // [13][gridDim.x * blockDim.x] parked dense outputs when the LDS is full (ZM == 2)
     const int* wave_map;  // [gridDim.x * waves_per_block] global wave of each slot, -1 = empty; null = strided deal
     int64_t max_steps;
@@ -312,6 +313,8 @@ struct Ctx {
     static constexpr bool ZS = (ZM == 1);
     const EnvDev& e;
     const double2* lds;  // LDS copy of the (single) depth profile when LDS_TAB
+    const double* bx;               // depth_ranges and depths: LDS copies when they fit, else HBM
+    const double* bd;
     const double* lds_z;            // ZM == 2: LDS copy of zin
     const unsigned short* lds_zb;   // ZM == 2: LDS copy of zbucket
     const double h_zb_z0, h_zb_inv_w;
@@ -326,8 +329,9 @@ struct Ctx {
     const double* const h_rin;
     const int h_nz, h_nr, h_r_uniform;
     __device__ __forceinline__ Ctx(const EnvDev& e_, const double2* l, const double* lz = nullptr,
-                                   const unsigned short* lzb = nullptr)
-        : e(e_), lds(l), lds_z(lz), lds_zb(lzb), h_zb_z0(e_.zb_z0), h_zb_inv_w(e_.zb_inv_w),
+                                   const unsigned short* lzb = nullptr, const double* lbx = nullptr)
+        : e(e_), lds(l), bx(lbx ? lbx : e_.depth_ranges), bd(lbx ? lbx + e_.nb : e_.depths), lds_z(lz),
+          lds_zb(lzb), h_zb_z0(e_.zb_z0), h_zb_inv_w(e_.zb_inv_w),
           h_zb_B(e_.zb_B), h_inv_dz(e_.inv_dz), h_dz(e_.dz), h_r0(e_.r0), h_dr(e_.dr),
           h_inv_dr(e_.inv_dr), h_rin(e_.rin), h_nz(e_.nz), h_nr(e_.nr), h_r_uniform(e_.r_uniform)
     {
@@ -451,12 +455,12 @@ struct Ctx {
             xi = grid_at(e.b0, e.db, i);
             xi1 = grid_at(e.b0, e.db, i + 1);
         } else {
-            i = cell_search(x, e.depth_ranges, e.nb);
-            xi = e.depth_ranges[i];
-            xi1 = e.depth_ranges[i + 1];
+            i = cell_search(x, bx, e.nb);
+            xi = bx[i];
+            xi1 = bx[i + 1];
         }
         double w = fdiv(x - xi, xi1 - xi);
-        return (1 - w) * e.depths[i] + w * e.depths[i + 1];
+        return (1 - w) * bd[i] + w * bd[i + 1];
     }
 
     // derivsrd, REF/integration_processes.py:26-98 (clamp: Q8)
@@ -702,8 +706,16 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
         for (int j = threadIdx.x; j < env.nz; j += blockDim.x) lds_z[j] = env.zin[j];
         for (int j = threadIdx.x; j < env.zb_B; j += blockDim.x) lds_zb[j] = env.zbucket[j];
     }
-    if (LDS_TAB || ZM == 2) __syncthreads();
-    const Ctx<LDS_TAB, ZM> C(env, lds_tab, lds_z, lds_zb);
+    // the bathymetry under a deep ray is looked up every step: {depth_ranges, depths} in LDS too
+    double* const lds_bx = (a.bathy_lds_off >= 0) ? (double*)((char*)lds_tab + a.bathy_lds_off) : nullptr;
+    if (lds_bx) {
+        for (int j = threadIdx.x; j < env.nb; j += blockDim.x) {
+            lds_bx[j] = env.depth_ranges[j];
+            lds_bx[env.nb + j] = env.depths[j];
+        }
+    }
+    __syncthreads();
+    const Ctx<LDS_TAB, ZM> C(env, lds_tab, lds_z, lds_zb, lds_bx);
     // waves are dealt to workgroups round-robin (wave w of block b = global wave w*grid + b):
     // neighbouring launch angles cost alike, so a strided deal balances the CUs
     int64_t gwave = (int64_t)(threadIdx.x >> 6) * gridDim.x + blockIdx.x;
@@ -1725,6 +1737,12 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
             env->park_slot_bytes = need;
         }
         a.park_ws = (double*)((char*)env->park_buf + (size_t)(env->park_next++ % pgr_env::kParkRing) * env->park_slot_bytes);
+    }
+    // {depth_ranges, depths} behind everything else in the LDS when 16 nb bytes are left
+    a.bathy_lds_off = -1;
+    {
+        const size_t at = (lds + 15) & ~(size_t)15, need = (size_t)D.nb * 16;
+        if (at + need <= env->max_lds) { a.bathy_lds_off = (int)at; lds = at + need; }
     }
 #define PGR_LAUNCH(LT, ZMV)                                                                          \
     do {                                                                                             \
