@@ -53,7 +53,8 @@ extern "C" {
                                       recomputes r_save[j] = j*step + start instead of loading it.
                                       The host entry sets/clears this bit itself after checking. */
 #define PGR_DEBUG_TRIPS 16u       /* diagnostics: n_rej[] receives, per wave, the number of main-loop
-                                      trips (lane 0) and of service phases (other lanes) instead */
+                                      trips (lane 0), of service phases (lane 1) and, per ray, how often
+                                      the exact event bisection ran (lanes 2..63) instead */
 
 #define PGR_EXACT_SAMPLES 32u      /* evaluate the saved samples with SciPy's own summation order
                                       (Q = K.T @ P, then h * (Q @ p) + y_old, SCIPY/rk.py:552-574)

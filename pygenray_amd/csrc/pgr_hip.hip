@@ -770,7 +770,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     double pk_tnew = 0;
     unsigned pk_active = 0;
     int waited = 0;
-    int trips = 0, services = 0;  // diagnostics (PGR_DEBUG_TRIPS)
+    int trips = 0, services = 0, fallbacks = 0;  // diagnostics (PGR_DEBUG_TRIPS)
     const int64_t out_off = ray * a.stride_ray;
 #define Tp (a.T + out_off)
 #define Zp (a.Z + out_off)
@@ -944,7 +944,11 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                     const double t_new = pk_tnew, h = D.h;
                     int ev = -1;
                     double best = 0;
-                    if ((a.flags & PGR_EXACT_BISECTION) == 0 && (active == 1u || active == 2u)) {
+                    // (a step that crosses the surface nearly always also crosses the bounding box's
+                    // z = zin[0] - 1e-6 just after it: both events are active, the surface flips first)
+                    const bool with_bbox = (active == 9u);
+                    const unsigned act = with_bbox ? 1u : active;
+                    if ((a.flags & PGR_EXACT_BISECTION) == 0 && (act == 1u || act == 2u)) {
                         // ---- fast event location (default) ----
                         // SciPy's brentq on the +-1 event degenerates to ~42 bisection steps, each a
                         // dense-output + table evaluation.  The flip of a surface/bottom event is the
@@ -954,7 +958,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                         // brentq's own final half-width 2 EPS (1 + |x|).  If they bracket the flip the
                         // answer x* + delta is within brentq's tolerance of SciPy's root; otherwise the
                         // exact bisection below runs.
-                        const bool bottom = (active == 2u);
+                        const bool bottom = (act == 2u);
                         const double q0 = D.q[1][0], q1 = D.q[1][1], q2 = D.q[1][2], q3 = D.q[1][3];
                         double bs = 0, be = 0;
                         if (bottom) { bs = C.bathy(t); be = C.bathy(t_new); }
@@ -975,7 +979,9 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                                 bool crossed = bottom ? (F > 0) : (F < 0);
                                 if (crossed) hi = sN; else lo = sN;
                                 double sn = sN - F / dF;
-                                if (!(sn > lo && sn < hi)) sn = 0.5 * (lo + hi);
+                                // (closed bracket: when F evaluates to exactly 0 the Newton step is
+                                // zero, sn == lo, and that is convergence, not an escape)
+                                if (!(sn >= lo && sn <= hi)) sn = 0.5 * (lo + hi);
                                 double ds = fabs(sn - sN);
                                 sN = sn;
                                 if (ds * h < 1e-12 * (1.0 + fabs(t))) break;
@@ -986,14 +992,18 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                             double ez0, ez1, ez2, ec, ecp;
                             D.eval(t, y0, y1, y2, xa, ez0, ez1, ez2);
                             C.lookup(xa, ez1, ec, ecp);
-                            bool ga = (C.events(xa, ez1, ez2, ec) & active) != 0;
+                            bool ga = (C.events(xa, ez1, ez2, ec) & act) != 0;
                             D.eval(t, y0, y1, y2, xb, ez0, ez1, ez2);
                             C.lookup(xb, ez1, ec, ecp);
-                            bool gb = (C.events(xb, ez1, ez2, ec) & active) != 0;
-                            if (!ga && gb) { best = xb; ev = bottom ? 1 : 0; }
+                            const unsigned bits_b = C.events(xb, ez1, ez2, ec);
+                            bool gb = (bits_b & act) != 0;
+                            // with the bounding-box event also active its flip must lie beyond xb, so
+                            // that the surface root is the earlier one (SCIPY/ivp.py:100-131)
+                            if (!ga && gb && !(with_bbox && (bits_b & 8u))) { best = xb; ev = bottom ? 1 : 0; }
                         }
                     }
                     if (ev < 0) {
+                        fallbacks++;
                         // handle_events + solve_event_equation, SCIPY/ivp.py:51-131: brentq(xtol =
                         // rtol = 4 EPS) on a +-1 step function == bisection (Q6).  All events are
                         // terminal: the earliest root wins, ties go to the lowest event index.
@@ -1157,7 +1167,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
         a.n_surf[ray] = ns;
         a.status[ray] = status;
         if (a.n_steps) a.n_steps[ray] = n_steps;
-        if (a.n_rej) a.n_rej[ray] = (a.flags & PGR_DEBUG_TRIPS) ? (((threadIdx.x & 63) == 0) ? trips : services) : n_rej;
+        if (a.n_rej) a.n_rej[ray] = (a.flags & PGR_DEBUG_TRIPS) ? (((threadIdx.x & 63) == 0) ? trips : (((threadIdx.x & 63) == 1) ? services : fallbacks)) : n_rej;
     }
 #undef Tp
 #undef Zp

@@ -14,10 +14,10 @@ for park in ((64, 64), (64, 16), (56, 64), (60, 64)):
     fan.flags |= 16; fan.run(); torch.cuda.synchronize()
     dbg = fan.n_rej.cpu().numpy()
     nw = len(att) // 64
-    a = att[:nw * 64].reshape(nw, 64); trips = dbg[:nw * 64].reshape(nw, 64)[:, 0]; serv = dbg[:nw * 64].reshape(nw, 64)[:, 1]
+    a = att[:nw * 64].reshape(nw, 64); trips = dbg[:nw * 64].reshape(nw, 64)[:, 0]; serv = dbg[:nw * 64].reshape(nw, 64)[:, 1]; fb = dbg[:nw * 64].reshape(nw, 64)[:, 2:]
     mx = a.max(1); mean = a.mean(1)
     for lo, hi, name in ((0, 40, "steepest 40 waves"), (700, 800, "middle waves")):
-        print(park, name, "trips", trips[lo:hi].mean().round(), "max-lane attempts", mx[lo:hi].mean().round(), "mean-lane attempts", mean[lo:hi].mean().round(), "services", serv[lo:hi].mean().round(), "overhead trips/max", (trips[lo:hi] / mx[lo:hi]).mean().round(3))
+        print(park, name, "trips", trips[lo:hi].mean().round(), "max-lane attempts", mx[lo:hi].mean().round(), "mean-lane attempts", mean[lo:hi].mean().round(), "services", serv[lo:hi].mean().round(), "exact-bisection fallbacks per wave (62 lanes)", fb[lo:hi].sum(1).mean().round(1), "overhead trips/max", (trips[lo:hi] / mx[lo:hi]).mean().round(3))
 print("---- whole-fan maxima")
 for park in ((64, 64), (64, 16), (64, 8), (64, 4)):
     _lib.set_park(*park)
@@ -26,7 +26,7 @@ for park in ((64, 64), (64, 16), (64, 8), (64, 4)):
     fan.flags |= 16; fan.run(); torch.cuda.synchronize()
     dbg = fan.n_rej.cpu().numpy()
     nw = len(att) // 64
-    a = att[:nw * 64].reshape(nw, 64); trips = dbg[:nw * 64].reshape(nw, 64)[:, 0]; serv = dbg[:nw * 64].reshape(nw, 64)[:, 1]
+    a = att[:nw * 64].reshape(nw, 64); trips = dbg[:nw * 64].reshape(nw, 64)[:, 0]; serv = dbg[:nw * 64].reshape(nw, 64)[:, 1]; fb = dbg[:nw * 64].reshape(nw, 64)[:, 2:]
     k = int(np.argmax(trips))
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     fan.flags &= ~16; e0.record(); fan.run(); e1.record(); torch.cuda.synchronize()
