@@ -83,7 +83,6 @@ struct FanArgs {
     int save_formula;  // r_save[j] == j*save_step + x0 bitwise (host verified)
     int park_lanes, park_trips;  // service batching thresholds
     int bathy_lds_off;    // byte offset of the LDS copy of {depth_ranges[nb], depths[nb]}, or -1 (read from HBM)
-    double* park_ws;      // [13][gridDim.x * blockDim.x] parked dense outputs when the LDS is full (ZM == 2)
     const int* wave_map;  // [gridDim.x * waves_per_block] global wave of each slot, -1 = empty; null = strided deal
     int64_t max_steps;
     uint32_t flags;
@@ -643,6 +642,35 @@ struct Dense {
         D.q[2][3] = PQ(f2, k32, k42, k52, k62, k72, 3);                                 \
     } while (0)
 
+// rk_step, SCIPY/rk.py:14-71 (K1 = f by FSAL): the six new stages of ONE attempt from (T_, y, f)
+// with step H_ -- defines k2*..k7* (k20 = dT/dx, k21 = dz/dx, k22 = dp/dx of stage 2, ...), y_new =
+// (n0, n1, n2) and c_new = c at (T_ + H_, y_new).  Used by the step attempt and, with the same
+// (t, y, f, h), by the service phase of a lane that parked on this step: IEEE arithmetic in a
+// fixed order, so the replay reproduces every bit and nothing has to be kept while parked.
+#define PGR_RK_STAGES(T_, H_)                                                                        \
+    double k20, k21, k22, k30, k31, k32, k40, k41, k42, k50, k51, k52, k60, k61, k62, k70, k71, k72, \
+        cs;                                                                                          \
+    double wr[5];                                                                                    \
+    int ir[5];                                                                                       \
+    C.step_weights(T_, H_, wr, ir);                                                                  \
+    C.rhs_w(wr[0], ir[0], y1 + (f1 * A21) * (H_), y2 + (f2 * A21) * (H_), k20, k21, k22, cs);        \
+    C.rhs_w(wr[1], ir[1], y1 + (f1 * A31 + k21 * A32) * (H_), y2 + (f2 * A31 + k22 * A32) * (H_),    \
+            k30, k31, k32, cs);                                                                      \
+    C.rhs_w(wr[2], ir[2], y1 + (f1 * A41 + k21 * A42 + k31 * A43) * (H_),                            \
+            y2 + (f2 * A41 + k22 * A42 + k32 * A43) * (H_), k40, k41, k42, cs);                      \
+    C.rhs_w(wr[3], ir[3], y1 + (f1 * A51 + k21 * A52 + k31 * A53 + k41 * A54) * (H_),                \
+            y2 + (f2 * A51 + k22 * A52 + k32 * A53 + k42 * A54) * (H_), k50, k51, k52, cs);          \
+    C.rhs_w(wr[4], ir[4], y1 + (f1 * A61 + k21 * A62 + k31 * A63 + k41 * A64 + k51 * A65) * (H_),    \
+            y2 + (f2 * A61 + k22 * A62 + k32 * A63 + k42 * A64 + k52 * A65) * (H_), k60, k61, k62,   \
+            cs);                                                                                     \
+    /* y_new = y + h * (K[:-1].T @ B)   (B[1] = 0) */                                                \
+    double n0 = y0 + (H_) * (f0 * B1 + k30 * B3 + k40 * B4 + k50 * B5 + k60 * B6);                   \
+    double n1 = y1 + (H_) * (f1 * B1 + k31 * B3 + k41 * B4 + k51 * B5 + k61 * B6);                   \
+    double n2 = y2 + (H_) * (f2 * B1 + k32 * B3 + k42 * B4 + k52 * B5 + k62 * B6);                   \
+    double c_new;                                                                                    \
+    /* f_new at t + h: the stage-6 abscissa */                                                       \
+    C.rhs_w(wr[4], ir[4], n1, n2, k70, k71, k72, c_new)
+
 // the save grid np.linspace(x0, x1, S): either recomputed per index exactly as NumPy does
 // (arange(S) * step + start, last point forced to x1 -- verified bitwise on the host) or loaded
 struct SaveGrid {
@@ -693,8 +721,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     // literals) into constant re-materialisation + SGPR spills inside the step loop
     const EnvDev& env = *env_p;
     extern __shared__ double2 lds_tab[];
-    // LDS layout: [{c, cp}[nz] when LDS_TAB][zin[nz], zbucket[zb_B] when ZM == 2][parked dense
-    // outputs, 13 doubles per lane, when ZM != 2]
+    // LDS layout: [{c, cp}[nz] when LDS_TAB][zin[nz], zbucket[zb_B] when ZM == 2][bathymetry]
     double* const lds_after_tab = (double*)(lds_tab + (LDS_TAB ? env.nz : 0));
     double* const lds_z = lds_after_tab;
     unsigned short* const lds_zb = (unsigned short*)(lds_z + env.nz);
@@ -759,14 +786,8 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     int nb = 0, ns = 0, n_steps = 0, n_rej = 0;
     int jnext = 0;
     double rnext = 0;
-    // A parked lane keeps the dense output of the step it is holding in LDS, 13 doubles per lane
-    // laid out [13][blockDim.x] behind the table (t_old = t, y_old = y stay live in registers):
-    // written once per boundary hit, read once per service, and 26 VGPRs less loop-carried state.
-    // (ZM == 2: zin and its bucket table take that LDS; the parked outputs go to a global
-    // workspace instead -- a boundary hit is rare enough for an L2 round trip)
-    const int pk_stride = (ZM == 2) ? (int)(gridDim.x * blockDim.x) : (int)blockDim.x;
-    double* const pk_lds = (ZM == 2) ? (a.park_ws + (size_t)blockIdx.x * blockDim.x + threadIdx.x)
-                                     : (lds_after_tab + threadIdx.x);
+    // a parked lane keeps only the end of its step and which events fired; the service phase
+    // replays the step (PGR_RK_STAGES) to get its dense output back
     double pk_tnew = 0;
     unsigned pk_active = 0;
     int waited = 0;
@@ -793,28 +814,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
             h = t_new - t;
             h_abs = fabs(h);
 
-            // rk_step, SCIPY/rk.py:14-71 (K1 = f by FSAL)
-            double k20, k21, k22, k30, k31, k32, k40, k41, k42, k50, k51, k52, k60, k61, k62, k70,
-                k71, k72, cs;
-            double wr[5];
-            int ir[5];
-            C.step_weights(t, h, wr, ir);
-            C.rhs_w(wr[0], ir[0], y1 + (f1 * A21) * h, y2 + (f2 * A21) * h, k20, k21, k22, cs);
-            C.rhs_w(wr[1], ir[1], y1 + (f1 * A31 + k21 * A32) * h, y2 + (f2 * A31 + k22 * A32) * h, k30,
-                    k31, k32, cs);
-            C.rhs_w(wr[2], ir[2], y1 + (f1 * A41 + k21 * A42 + k31 * A43) * h,
-                    y2 + (f2 * A41 + k22 * A42 + k32 * A43) * h, k40, k41, k42, cs);
-            C.rhs_w(wr[3], ir[3], y1 + (f1 * A51 + k21 * A52 + k31 * A53 + k41 * A54) * h,
-                    y2 + (f2 * A51 + k22 * A52 + k32 * A53 + k42 * A54) * h, k50, k51, k52, cs);
-            C.rhs_w(wr[4], ir[4], y1 + (f1 * A61 + k21 * A62 + k31 * A63 + k41 * A64 + k51 * A65) * h,
-                    y2 + (f2 * A61 + k22 * A62 + k32 * A63 + k42 * A64 + k52 * A65) * h, k60, k61, k62,
-                    cs);
-            // y_new = y + h * (K[:-1].T @ B)   (B[1] = 0)
-            double n0 = y0 + h * (f0 * B1 + k30 * B3 + k40 * B4 + k50 * B5 + k60 * B6);
-            double n1 = y1 + h * (f1 * B1 + k31 * B3 + k41 * B4 + k51 * B5 + k61 * B6);
-            double n2 = y2 + h * (f2 * B1 + k32 * B3 + k42 * B4 + k52 * B5 + k62 * B6);
-            double c_new;
-            C.rhs_w(wr[4], ir[4], n1, n2, k70, k71, k72, c_new);  // f_new at t + h: the stage-6 abscissa
+            PGR_RK_STAGES(t, h);
             // error estimate, SCIPY/rk.py:106-110,146-147  (E[1] = 0)
             double sc0 = atol + fmax(fabs(y0), fabs(n0)) * rtol;
             double sc1 = atol + fmax(fabs(y1), fabs(n1)) * rtol;
@@ -858,16 +858,11 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                 const bool scipy_order = exact_samples || (rnext < t);
                 Dense D;
                 if (active) {
-                    // park: the step is located, truncated and bounced in the next service phase
-                    PGR_FORM_Q();
+                    // park: the step is located, truncated and bounced in the next service phase, which
+                    // replays this attempt's stages from (t, y, f) and pk_tnew -- nothing else is kept
                     parked = true;
                     pk_active = active;
                     pk_tnew = t_new;
-                    pk_lds[0] = D.h;
-#pragma unroll
-                    for (int i = 0; i < 3; i++)
-#pragma unroll
-                        for (int j = 0; j < 4; j++) pk_lds[(size_t)(1 + 4 * i + j) * pk_stride] = D.q[i][j];
                 } else {
                     // ---- _interpolate_ray, streamed (REF/launch_rays.py:763-772, Q5): samples of the
                     // segment slice [idx1, idx2) that this step's quartic owns ----
@@ -935,13 +930,12 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                 if (pend && parked) {
                     parked = false;
                     const unsigned active = pk_active;
+                    // replay the parked attempt: same t, y, f and h = t_new - t as when it ran
+                    const double t_new = pk_tnew, h = t_new - t;
+                    PGR_RK_STAGES(t, h);
+                    (void)n0; (void)n1; (void)n2; (void)c_new;
                     Dense D;
-                    D.h = pk_lds[0];
-#pragma unroll
-                    for (int i = 0; i < 3; i++)
-#pragma unroll
-                        for (int j = 0; j < 4; j++) D.q[i][j] = pk_lds[(size_t)(1 + 4 * i + j) * pk_stride];
-                    const double t_new = pk_tnew, h = D.h;
+                    PGR_FORM_Q();
                     int ev = -1;
                     double best = 0;
                     // (a step that crosses the surface nearly always also crosses the bounding box's
@@ -1316,7 +1310,6 @@ __global__ void pgr_math_kernel(const double* a, const double* b, int64_t M, dou
 static thread_local std::string g_err;
 static int g_waves_per_block = 0;
 static int g_depth_search = 0;  // 0: automatic, 1: never use the bucketed search (tests)
-static const size_t PARK_BYTES = 13 * sizeof(double);  // h + Q[3][4] of a parked lane (LDS)
 static int g_park_lanes = 64, g_park_trips = 16;
 static int g_place = 2;  // 0 off, 1 issue priorities only, 2 cost-aware placement + priorities
 
@@ -1347,11 +1340,6 @@ struct pgr_env {
     size_t place_slot_bytes = 0;
     int place_next = 0;
     std::mutex place_mutex;
-    // ring of global workspaces for the parked dense outputs of bucketed-z launches
-    static constexpr int kParkRing = 4;
-    void* park_buf = nullptr;      // owned through `allocs`
-    size_t park_slot_bytes = 0;
-    int park_next = 0;
     int range_indep = 0;
     int lds_path = 0;
     std::vector<void*> allocs;
@@ -1520,8 +1508,7 @@ extern "C" int pgr_env_create(pgr_env** out, int device, const double* cin, cons
     std::vector<double2> tab(rows * (size_t)nz);
     for (size_t i = 0; i < rows; i++)
         for (int64_t j = 0; j < nz; j++) tab[i * nz + j] = make_double2(cin[i * nz + j], cpin[i * nz + j]);
-    // the LDS table needs room beside it for at least 4 waves' parked dense outputs
-    e->lds_path = indep && ((size_t)nz * sizeof(double2) + PARK_BYTES * 256 <= e->max_lds);
+    e->lds_path = indep && ((size_t)nz * sizeof(double2) <= e->max_lds);
     std::vector<double> pp;
     if (!build_notaknot(depth_ranges, bottom_angles, nb, pp)) {
         delete e;
@@ -1710,16 +1697,11 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
             if (wpb < 1) wpb = 1;
             if (wpb > 8) wpb = 8;
         }
-        if (zm != 2) {
-            // the table shares the LDS with the parked lanes' dense outputs (PARK_BYTES per lane)
-            const int wpb_fit = (int)((env->max_lds - tab_bytes) / (PARK_BYTES * 64));
-            if (wpb > wpb_fit) wpb = wpb_fit;
-        }
         threads = wpb * 64;
         blocks = (N + threads - 1) / threads;
         // cost-aware scheduling of the waves (placement, priorities, homogeneous workgroups)
         if (schedule_waves(env, y0, N, waves, wpb, st, a.wave_map, blocks)) return -1;
-        lds = tab_bytes + (zm == 2 ? zb_bytes : PARK_BYTES * (size_t)threads);
+        lds = tab_bytes + (zm == 2 ? zb_bytes : 0);
     } else {
         wpb = g_waves_per_block ? g_waves_per_block : 4;
         blocks = (waves + wpb - 1) / wpb;
@@ -1732,21 +1714,7 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
             if (m) { a.wave_map = m; blocks = nb2; wpb = W; }
         }
         threads = wpb * 64;
-        lds = (zm == 2) ? zb_bytes : PARK_BYTES * (size_t)threads;
-    }
-    if (zm == 2) {
-        // parked dense outputs in global memory: [13][blocks * threads] doubles from a small ring
-        // (launches of one env on different streams must not share a slot)
-        std::lock_guard<std::mutex> lock(env->place_mutex);
-        size_t need = (PARK_BYTES * (size_t)blocks * (size_t)threads + 255) & ~(size_t)255;
-        if (need > env->park_slot_bytes) {
-            void* nb = nullptr;
-            HIPCHK(hipMalloc(&nb, need * pgr_env::kParkRing));
-            env->allocs.push_back(nb);
-            env->park_buf = nb;
-            env->park_slot_bytes = need;
-        }
-        a.park_ws = (double*)((char*)env->park_buf + (size_t)(env->park_next++ % pgr_env::kParkRing) * env->park_slot_bytes);
+        lds = (zm == 2) ? zb_bytes : 0;
     }
     // {depth_ranges, depths} behind everything else in the LDS when 16 nb bytes are left
     a.bathy_lds_off = -1;
