@@ -653,16 +653,26 @@ struct Dense {
     double wr[5];                                                                                    \
     int ir[5];                                                                                       \
     C.step_weights(T_, H_, wr, ir);                                                                  \
+    /* the stage sums sum_j A[s][j] K_j are accumulated term by term as each K_j arrives (the same   \
+       additions in the same order as SciPy's dot product): the terms of LATER stages are then free  \
+       work for the shadow of the next stage's table read */                                         \
+    double a31 = f1 * A31, a32 = f2 * A31, a41 = f1 * A41, a42 = f2 * A41, a51 = f1 * A51,           \
+           a52 = f2 * A51, a61 = f1 * A61, a62 = f2 * A61;                                           \
     C.rhs_w(wr[0], ir[0], y1 + (f1 * A21) * (H_), y2 + (f2 * A21) * (H_), k20, k21, k22, cs);        \
-    C.rhs_w(wr[1], ir[1], y1 + (f1 * A31 + k21 * A32) * (H_), y2 + (f2 * A31 + k22 * A32) * (H_),    \
-            k30, k31, k32, cs);                                                                      \
-    C.rhs_w(wr[2], ir[2], y1 + (f1 * A41 + k21 * A42 + k31 * A43) * (H_),                            \
-            y2 + (f2 * A41 + k22 * A42 + k32 * A43) * (H_), k40, k41, k42, cs);                      \
-    C.rhs_w(wr[3], ir[3], y1 + (f1 * A51 + k21 * A52 + k31 * A53 + k41 * A54) * (H_),                \
-            y2 + (f2 * A51 + k22 * A52 + k32 * A53 + k42 * A54) * (H_), k50, k51, k52, cs);          \
-    C.rhs_w(wr[4], ir[4], y1 + (f1 * A61 + k21 * A62 + k31 * A63 + k41 * A64 + k51 * A65) * (H_),    \
-            y2 + (f2 * A61 + k22 * A62 + k32 * A63 + k42 * A64 + k52 * A65) * (H_), k60, k61, k62,   \
-            cs);                                                                                     \
+    a31 = a31 + k21 * A32; a32 = a32 + k22 * A32;                                                    \
+    a41 = a41 + k21 * A42; a42 = a42 + k22 * A42;                                                    \
+    a51 = a51 + k21 * A52; a52 = a52 + k22 * A52;                                                    \
+    a61 = a61 + k21 * A62; a62 = a62 + k22 * A62;                                                    \
+    C.rhs_w(wr[1], ir[1], y1 + a31 * (H_), y2 + a32 * (H_), k30, k31, k32, cs);                      \
+    a41 = a41 + k31 * A43; a42 = a42 + k32 * A43;                                                    \
+    a51 = a51 + k31 * A53; a52 = a52 + k32 * A53;                                                    \
+    a61 = a61 + k31 * A63; a62 = a62 + k32 * A63;                                                    \
+    C.rhs_w(wr[2], ir[2], y1 + a41 * (H_), y2 + a42 * (H_), k40, k41, k42, cs);                      \
+    a51 = a51 + k41 * A54; a52 = a52 + k42 * A54;                                                    \
+    a61 = a61 + k41 * A64; a62 = a62 + k42 * A64;                                                    \
+    C.rhs_w(wr[3], ir[3], y1 + a51 * (H_), y2 + a52 * (H_), k50, k51, k52, cs);                      \
+    a61 = a61 + k51 * A65; a62 = a62 + k52 * A65;                                                    \
+    C.rhs_w(wr[4], ir[4], y1 + a61 * (H_), y2 + a62 * (H_), k60, k61, k62, cs);                      \
     /* y_new = y + h * (K[:-1].T @ B)   (B[1] = 0) */                                                \
     double n0 = y0 + (H_) * (f0 * B1 + k30 * B3 + k40 * B4 + k50 * B5 + k60 * B6);                   \
     double n1 = y1 + (H_) * (f1 * B1 + k31 * B3 + k41 * B4 + k51 * B5 + k61 * B6);                   \
