@@ -393,11 +393,16 @@ struct Ctx {
         lookup_w(wx, i, z, c, cp);
     }
     // the same with the range weight and range cell already known (step_weights)
-    __device__ __forceinline__ void lookup_w(double wx, int i, double z, double& c, double& cp) const
-    {
-        int j;
+    // the four corner nodes {c, cp} of the cell of (range cell i, z) and the depth weight: the
+    // memory half of a look-up, issued as early as the stage's z is known ...
+    struct Fetch {
+        double2 v00, v01, v10, v11;
         double wy;
-        double2 pre00 = {0, 0}, pre01 = {0, 0};  // ZM == 2 with the LDS table: nodes already fetched
+    };
+    __device__ __forceinline__ Fetch fetch(int i, double z) const
+    {
+        Fetch f;
+        int j;
         if (ZM == 2) {
             // bin -> candidate cell j0 (zin[j0] < every z of the bin <= zin[j0 + 2]); the three
             // nodes from j0 on are fetched together, then z > zin[j0 + 1] picks the upper cell
@@ -409,39 +414,51 @@ struct Ctx {
             const bool up = (z > zb) & (j0 + 1 <= h_nz - 2);
             j = j0 + (up ? 1 : 0);
             const double zj = up ? zb : za, zj1 = up ? zc : zb;
-            wy = fdiv(z - zj, zj1 - zj);
+            f.wy = fdiv(z - zj, zj1 - zj);
             if (LDS_TAB) {
                 const double2 t0 = lds[j0], t1 = lds[j0 + 1], t2 = lds[j2];
-                pre00 = up ? t1 : t0;
-                pre01 = up ? t2 : t1;
+                f.v00 = up ? t1 : t0;
+                f.v01 = up ? t2 : t1;
+                f.v10 = f.v00; f.v11 = f.v01;
+                return f;
             }
         } else if (ZS) {
             double t = z * h_inv_dz;                     // exact
             // v_cvt_i32_f64 saturates and maps NaN to 0: no clamp needed before the conversion
             j = min(max((int)ceil(t) - 1, 0), h_nz - 2);
-            wy = (z - (double)j * h_dz) * h_inv_dz;      // (z - zin[j]) / dz, exact scaling
+            f.wy = (z - (double)j * h_dz) * h_inv_dz;    // (z - zin[j]) / dz, exact scaling
         } else {
             double zj, zj1;
             j = cell_z(z, zj, zj1);
             // every cell exactly dz wide and dz a power of two: the division is an exact scaling
-            wy = e.z_pow2 ? (z - zj) * e.inv_dz : fdiv(z - zj, zj1 - zj);
+            f.wy = e.z_pow2 ? (z - zj) * e.inv_dz : fdiv(z - zj, zj1 - zj);
         }
-        double2 v00, v01, v10, v11;
         if (LDS_TAB) {
-            if (ZM == 2) { v00 = pre00; v01 = pre01; }
-            else { v00 = lds[j]; v01 = lds[j + 1]; }
-            v10 = v00;  // range independent: rows are bitwise identical
-            v11 = v01;
+            f.v00 = lds[j];
+            f.v01 = lds[j + 1];
+            f.v10 = f.v00;  // range independent: rows are bitwise identical
+            f.v11 = f.v01;
         } else {
             const double2* row = e.tab + (size_t)i * e.row_stride + j;
-            v00 = row[0];
-            v01 = row[1];
-            v10 = row[e.row_stride];
-            v11 = row[e.row_stride + 1];
+            f.v00 = row[0];
+            f.v01 = row[1];
+            f.v10 = row[e.row_stride];
+            f.v11 = row[e.row_stride + 1];
         }
+        return f;
+    }
+    // ... and the arithmetic half: the reference's four-corner blend
+    __device__ __forceinline__ void blend(const Fetch& f, double wx, double& c, double& cp) const
+    {
+        const double wy = f.wy;
         double a = (1 - wx) * (1 - wy), b = wx * (1 - wy), cc = (1 - wx) * wy, d = wx * wy;
-        c = a * v00.x + b * v10.x + cc * v01.x + d * v11.x;
-        cp = a * v00.y + b * v10.y + cc * v01.y + d * v11.y;
+        c = a * f.v00.x + b * f.v10.x + cc * f.v01.x + d * f.v11.x;
+        cp = a * f.v00.y + b * f.v10.y + cc * f.v01.y + d * f.v11.y;
+    }
+    __device__ __forceinline__ void lookup_w(double wx, int i, double z, double& c, double& cp) const
+    {
+        const Fetch f = fetch(i, z);
+        blend(f, wx, c, cp);
     }
 
     // bathymetry under the ray: linear_interp, REF/integration_processes.py:177-235
@@ -473,8 +490,13 @@ struct Ctx {
     __device__ __forceinline__ void rhs_w(double wx, int i, double z, double pz, double& d0, double& d1,
                                           double& d2, double& c) const
     {
+        rhs_f(fetch(i, z), wx, pz, d0, d1, d2, c);
+    }
+    __device__ __forceinline__ void rhs_f(const Fetch& ft, double wx, double pz, double& d0, double& d1,
+                                          double& d2, double& c) const
+    {
         double cp;
-        lookup_w(wx, i, z, c, cp);
+        blend(ft, wx, c, cp);
         double arg = 1.0 - (c * c) * (pz * pz);
         if (arg <= 0.0) arg = 1e-30;
 #if PGR_FAST
@@ -647,39 +669,76 @@ struct Dense {
 // (n0, n1, n2) and c_new = c at (T_ + H_, y_new).  Used by the step attempt and, with the same
 // (t, y, f, h), by the service phase of a lane that parked on this step: IEEE arithmetic in a
 // fixed order, so the replay reproduces every bit and nothing has to be kept while parked.
+#define PGR_SB() __builtin_amdgcn_sched_barrier(0)
 #define PGR_RK_STAGES(T_, H_)                                                                        \
     double k20, k21, k22, k30, k31, k32, k40, k41, k42, k50, k51, k52, k60, k61, k62, k70, k71, k72, \
         cs;                                                                                          \
     double wr[5];                                                                                    \
     int ir[5];                                                                                       \
     C.step_weights(T_, H_, wr, ir);                                                                  \
-    /* the stage sums sum_j A[s][j] K_j are accumulated term by term as each K_j arrives (the same   \
-       additions in the same order as SciPy's dot product): the terms of LATER stages are then free  \
-       work for the shadow of the next stage's table read */                                         \
+    /* Every sum over stages -- sum_j A[s][j] K_j, K.T @ B, K.T @ E -- is accumulated term by term   \
+       as each K_j arrives: the same additions in the same order as SciPy's dot products.  The       \
+       terms that the NEXT stage does not need sit between the issue of that stage's table read      \
+       (fetch) and its first use (rhs_f), fenced by scheduling barriers: ~90 cycles of read latency  \
+       per stage that a single in-order wave would otherwise idle through. */                       \
+    const double zs2 = y1 + (f1 * A21) * (H_), ps2 = y2 + (f2 * A21) * (H_);                         \
+    const auto ft2 = C.fetch(ir[0], zs2);                                                            \
+    PGR_SB();                                                                                        \
     double a31 = f1 * A31, a32 = f2 * A31, a41 = f1 * A41, a42 = f2 * A41, a51 = f1 * A51,           \
            a52 = f2 * A51, a61 = f1 * A61, a62 = f2 * A61;                                           \
-    C.rhs_w(wr[0], ir[0], y1 + (f1 * A21) * (H_), y2 + (f2 * A21) * (H_), k20, k21, k22, cs);        \
+    double bs0 = f0 * B1, bs1 = f1 * B1, bs2 = f2 * B1, es0 = f0 * E1, es1 = f1 * E1, es2 = f2 * E1; \
+    PGR_SB();                                                                                        \
+    C.rhs_f(ft2, wr[0], ps2, k20, k21, k22, cs);                                                     \
     a31 = a31 + k21 * A32; a32 = a32 + k22 * A32;                                                    \
+    const double zs3 = y1 + a31 * (H_), ps3 = y2 + a32 * (H_);                                       \
+    const auto ft3 = C.fetch(ir[1], zs3);                                                            \
+    PGR_SB();                                                                                        \
     a41 = a41 + k21 * A42; a42 = a42 + k22 * A42;                                                    \
     a51 = a51 + k21 * A52; a52 = a52 + k22 * A52;                                                    \
     a61 = a61 + k21 * A62; a62 = a62 + k22 * A62;                                                    \
-    C.rhs_w(wr[1], ir[1], y1 + a31 * (H_), y2 + a32 * (H_), k30, k31, k32, cs);                      \
+    PGR_SB();                                                                                        \
+    C.rhs_f(ft3, wr[1], ps3, k30, k31, k32, cs);                                                     \
     a41 = a41 + k31 * A43; a42 = a42 + k32 * A43;                                                    \
+    const double zs4 = y1 + a41 * (H_), ps4 = y2 + a42 * (H_);                                       \
+    const auto ft4 = C.fetch(ir[2], zs4);                                                            \
+    PGR_SB();                                                                                        \
     a51 = a51 + k31 * A53; a52 = a52 + k32 * A53;                                                    \
     a61 = a61 + k31 * A63; a62 = a62 + k32 * A63;                                                    \
-    C.rhs_w(wr[2], ir[2], y1 + a41 * (H_), y2 + a42 * (H_), k40, k41, k42, cs);                      \
+    bs0 = bs0 + k30 * B3; bs1 = bs1 + k31 * B3; bs2 = bs2 + k32 * B3;                                \
+    es0 = es0 + k30 * E3; es1 = es1 + k31 * E3; es2 = es2 + k32 * E3;                                \
+    PGR_SB();                                                                                        \
+    C.rhs_f(ft4, wr[2], ps4, k40, k41, k42, cs);                                                     \
     a51 = a51 + k41 * A54; a52 = a52 + k42 * A54;                                                    \
+    const double zs5 = y1 + a51 * (H_), ps5 = y2 + a52 * (H_);                                       \
+    const auto ft5 = C.fetch(ir[3], zs5);                                                            \
+    PGR_SB();                                                                                        \
     a61 = a61 + k41 * A64; a62 = a62 + k42 * A64;                                                    \
-    C.rhs_w(wr[3], ir[3], y1 + a51 * (H_), y2 + a52 * (H_), k50, k51, k52, cs);                      \
+    bs0 = bs0 + k40 * B4; bs1 = bs1 + k41 * B4; bs2 = bs2 + k42 * B4;                                \
+    es0 = es0 + k40 * E4; es1 = es1 + k41 * E4; es2 = es2 + k42 * E4;                                \
+    PGR_SB();                                                                                        \
+    C.rhs_f(ft5, wr[3], ps5, k50, k51, k52, cs);                                                     \
     a61 = a61 + k51 * A65; a62 = a62 + k52 * A65;                                                    \
-    C.rhs_w(wr[4], ir[4], y1 + a61 * (H_), y2 + a62 * (H_), k60, k61, k62, cs);                      \
+    const double zs6 = y1 + a61 * (H_), ps6 = y2 + a62 * (H_);                                       \
+    const auto ft6 = C.fetch(ir[4], zs6);                                                            \
+    PGR_SB();                                                                                        \
+    bs0 = bs0 + k50 * B5; bs1 = bs1 + k51 * B5; bs2 = bs2 + k52 * B5;                                \
+    es0 = es0 + k50 * E5; es1 = es1 + k51 * E5; es2 = es2 + k52 * E5;                                \
+    PGR_SB();                                                                                        \
+    C.rhs_f(ft6, wr[4], ps6, k60, k61, k62, cs);                                                     \
     /* y_new = y + h * (K[:-1].T @ B)   (B[1] = 0) */                                                \
-    double n0 = y0 + (H_) * (f0 * B1 + k30 * B3 + k40 * B4 + k50 * B5 + k60 * B6);                   \
-    double n1 = y1 + (H_) * (f1 * B1 + k31 * B3 + k41 * B4 + k51 * B5 + k61 * B6);                   \
-    double n2 = y2 + (H_) * (f2 * B1 + k32 * B3 + k42 * B4 + k52 * B5 + k62 * B6);                   \
-    double c_new;                                                                                    \
+    bs1 = bs1 + k61 * B6; bs2 = bs2 + k62 * B6;                                                      \
+    const double n1 = y1 + (H_) * bs1, n2 = y2 + (H_) * bs2;                                         \
     /* f_new at t + h: the stage-6 abscissa */                                                       \
-    C.rhs_w(wr[4], ir[4], n1, n2, k70, k71, k72, c_new)
+    const auto ft7 = C.fetch(ir[4], n1);                                                             \
+    PGR_SB();                                                                                        \
+    bs0 = bs0 + k60 * B6;                                                                            \
+    const double n0 = y0 + (H_) * bs0;                                                               \
+    es0 = es0 + k60 * E6; es1 = es1 + k61 * E6; es2 = es2 + k62 * E6;                                \
+    PGR_SB();                                                                                        \
+    double c_new;                                                                                    \
+    C.rhs_f(ft7, wr[4], n2, k70, k71, k72, c_new);                                                   \
+    /* K.T @ E complete (E[1] = 0), SCIPY/rk.py:106-110 */                                           \
+    es0 = es0 + k70 * E7; es1 = es1 + k71 * E7; es2 = es2 + k72 * E7
 
 // the save grid np.linspace(x0, x1, S): either recomputed per index exactly as NumPy does
 // (arange(S) * step + start, last point forced to x1 -- verified bitwise on the host) or loaded
@@ -829,9 +888,9 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
             double sc0 = atol + fmax(fabs(y0), fabs(n0)) * rtol;
             double sc1 = atol + fmax(fabs(y1), fabs(n1)) * rtol;
             double sc2 = atol + fmax(fabs(y2), fabs(n2)) * rtol;
-            double er0 = fdiv((f0 * E1 + k30 * E3 + k40 * E4 + k50 * E5 + k60 * E6 + k70 * E7) * h, sc0);
-            double er1 = fdiv((f1 * E1 + k31 * E3 + k41 * E4 + k51 * E5 + k61 * E6 + k71 * E7) * h, sc1);
-            double er2 = fdiv((f2 * E1 + k32 * E3 + k42 * E4 + k52 * E5 + k62 * E6 + k72 * E7) * h, sc2);
+            double er0 = fdiv(es0 * h, sc0);
+            double er1 = fdiv(es1 * h, sc1);
+            double er2 = fdiv(es2 * h, sc2);
             double error_norm = rms3(er0, er1, er2);
 
             // ---- accept / reject and the next step size, SCIPY/rk.py:148-165, without branches: a
@@ -943,7 +1002,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                     // replay the parked attempt: same t, y, f and h = t_new - t as when it ran
                     const double t_new = pk_tnew, h = t_new - t;
                     PGR_RK_STAGES(t, h);
-                    (void)n0; (void)n1; (void)n2; (void)c_new;
+                    (void)n0; (void)c_new; (void)es0; (void)es1; (void)es2;
                     Dense D;
                     PGR_FORM_Q();
                     int ev = -1;
