@@ -13,12 +13,14 @@
 //
 // Layout: the c and dc/dz tables are interleaved node-wise as double2 {c, cp} so one
 // 16-byte access fetches both values of a node; for range-independent tables the single
-// depth profile (nz x 16 B, 96 KB at nz = 6000) is staged into LDS once per workgroup.
+// depth profile (nz x 16 B, 96 KB at nz = 6000) is staged into LDS once per workgroup, next
+// to zin and its bucket table when the depth grid is not uniform, and the bathymetry.
 // State (x, y, f, h, K1..K7) lives in VGPRs.  No MFMA: there is no contraction here.
 //
-// Arithmetic is written in the reference's operation order and compiled with
-// -ffp-contract=off; IEEE fp64 divide / sqrt are correctly rounded on gfx950, so the
-// only non-bit-identical operations w.r.t. the CPU oracle are pow / asin / sin (libm vs ocml).
+// Arithmetic that feeds back into the integration is written in the reference's operation
+// order and compiled with -ffp-contract=off; divide / sqrt are correctly rounded, so the only
+// operations that are not bit-identical to the CPU oracle are err^-0.2 / asin / sin (libm vs
+// ocml / Newton) and the default event locator (a root within brentq's tolerance of SciPy's).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -776,10 +778,15 @@ struct SaveGrid {
 // -- locating the event on the dense output, re-sampling up to it, the reflection law and the
 // restart of the integrator (2 more RHS evaluations, pow, asin/sin) -- costs about two step
 // attempts and would run with one or two live lanes per trip if it were done on the spot.
-// Instead a lane that accepted a step with an active event PARKS: it keeps the step's dense
-// output in registers and stops stepping until the wave runs a SERVICE phase for all parked
-// lanes together (when `park_lanes` lanes wait, or the oldest has waited `park_trips` trips, or
-// nobody else can step).  Per-ray arithmetic is unchanged by when the service runs.
+// Instead a lane that accepted a step with an active event PARKS: it keeps (t, y, f) of the
+// step's start, the step's end and the fired events, and stops stepping until the wave runs a
+// SERVICE phase for all parked lanes together (when `park_lanes` lanes wait, or the oldest has
+// waited `park_trips` trips, or nobody else can step); the service replays the step's stages to
+// get the dense output back.  Per-ray arithmetic is unchanged by when the service runs.
+//
+// Control flow inside a trip is kept free of skipped blocks (a taken skip-branch costs a lone
+// wave ~80 cycles): selects where both sides are cheap, ONE block per kind of rare work, and
+// the memory half of each table look-up issued early with independent work behind it.
 // ------------------------------------------------------------------------------------
 template <bool LDS_TAB, int ZM>
 __global__ void __launch_bounds__(512)
