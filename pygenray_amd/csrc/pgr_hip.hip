@@ -878,6 +878,11 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     // need_init.)  The step comes first so that the common path -- nobody parked -- is the loop's
     // fall-through: one skipped block and the back-edge are its only taken branches.
     do {
+        bool run, pend;
+        unsigned long long pm;
+        // inner loop: step attempts while no lane is waiting for service (the common case: its
+        // only taken branch is its own back-edge)
+        do {
         trips++;
         if (status == RUNNING && !parked && !need_init) {
             // ---- one attempt of RK45._step_impl, SCIPY/rk.py:111-176 ----
@@ -993,9 +998,10 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                 }
             }
         }
-        const bool run = (status == RUNNING);
-        const bool pend = run && (parked || need_init);
-        const unsigned long long pm = __ballot(pend);
+        run = (status == RUNNING);
+        pend = run && (parked || need_init);
+        pm = __ballot(pend);
+        } while (pm == 0 && __any(run));
         if (pm) {
             waited++;
             const bool nobody_steps = !__any(run && !pend);
