@@ -327,6 +327,7 @@ struct Ctx {
     // wave-uniform copies of the fields the step loop touches (kept in SGPRs; the rest of the
     // descriptor is read from memory where it is needed)
     const double h_inv_dz, h_dz, h_r0, h_dr, h_inv_dr;
+    const double h_b_zmin, h_b_xlo, h_b_xhi, h_zhi_tol, h_zlo_tol, h_rlo_tol, h_rhi_tol;  // events()
     const double* const h_rin;
     const int h_nz, h_nr, h_r_uniform;
     __device__ __forceinline__ Ctx(const EnvDev& e_, const double2* l, const double* lz = nullptr,
@@ -334,6 +335,8 @@ struct Ctx {
         : e(e_), lds(l), bx(lbx ? lbx : e_.depth_ranges), bd(lbx ? lbx + e_.nb : e_.depths), lds_z(lz),
           lds_zb(lzb), h_zb_z0(e_.zb_z0), h_zb_inv_w(e_.zb_inv_w),
           h_zb_B(e_.zb_B), h_inv_dz(e_.inv_dz), h_dz(e_.dz), h_r0(e_.r0), h_dr(e_.dr),
+          h_b_zmin(e_.b_zmin), h_b_xlo(e_.b_xlo), h_b_xhi(e_.b_xhi), h_zhi_tol(e_.zhi_tol),
+          h_zlo_tol(e_.zlo_tol), h_rlo_tol(e_.rlo_tol), h_rhi_tol(e_.rhi_tol),
           h_inv_dr(e_.inv_dr), h_rin(e_.rin), h_nz(e_.nz), h_nr(e_.nr), h_r_uniform(e_.r_uniform)
     {
         r_lo = 1.0; r_hi = 0.0; r_yden = 1.0; r_hi2 = 0.0; r_i = 0;  // empty interval: first use refills
@@ -575,7 +578,7 @@ struct Ctx {
         // (minus a margin for the interpolation's rounding) and x is inside the bathymetry table;
         // vertical: only |pc| within 2e-10 of 1 can reach 90 - 1e-3 degrees.  Both tests sit in ONE
         // rarely entered block: every skipped block is a taken branch on the step's critical path.
-        const bool near_bottom = (pc > 0) & (pc <= 1.0) & !((z < e.b_zmin) & (x >= e.b_xlo) & (x <= e.b_xhi));
+        const bool near_bottom = (pc > 0) & (pc <= 1.0) & !((z < h_b_zmin) & (x >= h_b_xlo) & (x <= h_b_xhi));
         const bool near_vertical = (fabs(pc) > 0.9999999998) & (fabs(pc) <= 1.0);
         if (near_bottom | near_vertical) {
             if (near_bottom) {
@@ -586,7 +589,7 @@ struct Ctx {
                 if (fabs(th) > (90 - 1e-3)) g |= 4u;
             }
         }
-        if ((z > e.zhi_tol) | (z < e.zlo_tol) | (x < e.rlo_tol) | (x > e.rhi_tol)) g |= 8u;
+        if ((z > h_zhi_tol) | (z < h_zlo_tol) | (x < h_rlo_tol) | (x > h_rhi_tol)) g |= 8u;
         return g;
     }
 };
