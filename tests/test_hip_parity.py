@@ -189,6 +189,27 @@ def test_nonuniform_grids_generic_search_path(lib):
     gpu_vs_oracle(lib, arrs, y0, 0.0, 80e3, 81, "non-uniform grids")
 
 
+def test_steps_wider_than_range_cells(lib):
+    """The range weights of a step's five stage abscissae are computed together from the cached
+    cell, its right neighbour, or cell by cell: a 100 m range grid under loose-tolerance steps
+    of several hundred metres (every step straddles cells, many span more than two), uniform
+    and non-uniform rin, range independent and dependent."""
+    r_u = np.linspace(0.0, 100e3, 1001)
+    r_n = np.sort(np.concatenate([[0.0, 100e3], np.random.default_rng(5).uniform(0, 100e3, 700)]))
+    z = np.arange(0, 6000, 1.0)
+    for r, slope in ((r_u, 0.0), (r_u, 1e-3), (r_n, 1e-3)):
+        cin = np.array([munk(z, 1300 + slope * ri) for ri in r])
+        arrs = [cin, np.gradient(cin, z, axis=1, edge_order=1), r, z, np.full(len(r), 5000.0), r.copy(),
+                np.zeros(len(r))]
+        y0 = y0_for(oracle, arrs, 1000.0, 0.0, np.linspace(-18, 18, 130))
+        for rtol in (1e-5, 1e-9):
+            # at rtol = 1e-5 the solution itself is only good to ~1e-5: last-bit differences of the
+            # step-size sequence show at the 1e-8 level, so the reference's own test tolerances apply
+            floor = dict(T=1e-6, z=1e-2, p=1e-7) if rtol > 1e-8 else None
+            gpu_vs_oracle(lib, arrs, y0, 0.0, 100e3, 41, f"fine range grid rtol={rtol}", rtol=rtol,
+                          abs_floor=floor)
+
+
 def test_dropped_rays_and_statuses(lib):
     # backward bounce off a wall, bbox exit, near-vertical rays: same statuses as the oracle
     arrs = munk_arrays(50e3, nr=20, z=np.linspace(0, 6000, 601))
