@@ -1303,9 +1303,20 @@ pgr_wave_place(const float* __restrict__ cost, int n_waves, int B, int W, int mo
     for (int i = threadIdx.x; i < n_waves; i += blockDim.x)
         atomicAdd(&bins[min(NB - 1, (int)(cost[i] * scale))], 1);
     __syncthreads();
-    if (threadIdx.x == 0) {       // exclusive prefix, most expensive bin first
-        int acc = 0;
-        for (int k = NB - 1; k >= 0; k--) { int c = bins[k]; bins[k] = acc; acc += c; }
+    {   // exclusive prefix over the bins, most expensive bin first: 4 bins per thread + a block scan
+        __shared__ int part[1024];
+        const int t = threadIdx.x, hi = NB - 1 - 4 * t;   // this thread's bins: hi, hi-1, hi-2, hi-3
+        const int c0 = bins[hi], c1 = bins[hi - 1], c2 = bins[hi - 2], c3 = bins[hi - 3];
+        part[t] = c0 + c1 + c2 + c3;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {               // Hillis-Steele inclusive scan
+            int v = (t >= o) ? part[t - o] : 0;
+            __syncthreads();
+            part[t] += v;
+            __syncthreads();
+        }
+        const int ex = part[t] - (c0 + c1 + c2 + c3);
+        bins[hi] = ex; bins[hi - 1] = ex + c0; bins[hi - 2] = ex + c0 + c1; bins[hi - 3] = ex + c0 + c1 + c2;
     }
     __syncthreads();
     const int lone_per_block = 8 - W;                 // waves W-4 .. 3
