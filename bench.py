@@ -114,7 +114,7 @@ def main():
     import torch.distributed as dist
     from pygenray_amd import _lib
     from pygenray_amd.device_fan import DeviceFan, fan_y0
-    from pygenray_amd.distributed import shard_indices, all_gather_fan
+    from pygenray_amd.distributed import shard_indices, all_gather_fan, start_all_gather_fan
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -160,12 +160,20 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
     t0 = time.perf_counter()
+    pending = None
     for k in range(args.steps):
         ev[k][0].record()
         fan.run()
         ev[k][1].record()
         if use_dist:
-            all_gather_fan(fan.end, fan.n_bott, fan.n_surf, fan.status, n_global)
+            # the end records of pass k travel (RCCL stream) while pass k+1 integrates; every
+            # gathered fan is reassembled in launch-angle order before the clock stops
+            started = start_all_gather_fan(fan.end, fan.n_bott, fan.n_surf, fan.status, n_global)
+            if pending is not None:
+                pending.finish()
+            pending = started
+    if pending is not None:
+        pending.finish()
     fence()
     dt = time.perf_counter() - t0
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))

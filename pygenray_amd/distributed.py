@@ -33,22 +33,43 @@ def pack_end_records(end, n_bott, n_surf, status, n_pad):
     return buf
 
 
-def all_gather_fan(end, n_bott, n_surf, status, n_rays, group=None):
-    """All-gather the local end records and return them in global launch-angle order:
-    ``(end [N,3] float64, n_bott [N], n_surf [N], status [N])`` on every rank."""
+class FanGather:
+    """An all-gather of end records in flight (``start_all_gather_fan``): ``finish()`` makes the
+    current stream wait for it and returns the fan in global launch-angle order."""
+
+    def __init__(self, work, gathered, world, n_pad, n_rays, keep):
+        self.work, self.gathered, self.world, self.n_pad, self.n_rays = work, gathered, world, n_pad, n_rays
+        self._keep = keep  # the packed send buffer must outlive the collective
+
+    def finish(self):
+        if self.work is not None:
+            self.work.wait()   # stream-ordered for RCCL: the host does not block
+            self.work = None
+        # rank r holds global rays r, r+W, r+2W, ... -> interleave back
+        full = self.gathered.permute(1, 0, 2).reshape(self.world * self.n_pad, 5)[:self.n_rays]
+        ints = full[:, 3:5].contiguous().view(torch.int32)
+        return (full[:, 0:3].contiguous(), ints[:, 0].contiguous(), ints[:, 1].contiguous(),
+                ints[:, 2].contiguous())
+
+
+def start_all_gather_fan(end, n_bott, n_surf, status, n_rays, group=None):
+    """Pack the local end records and START their all-gather (asynchronous: the collective runs
+    on RCCL's stream behind the work already queued, so the next fan can be launched while the
+    records travel).  The inputs may be overwritten as soon as this returns (they are copied)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     n_pad = (n_rays + world - 1) // world
     local = pack_end_records(end, n_bott, n_surf, status, n_pad)
     if dist.is_initialized():  # also with a single rank: the collective is then a copy
         flat = torch.empty((world * n_pad, 5), dtype=torch.float64, device=local.device)
-        dist.all_gather_into_tensor(flat, local, group=group)
-        gathered = flat.view(world, n_pad, 5)
-    else:
-        gathered = local.unsqueeze(0)
-    # rank r holds global rays r, r+W, r+2W, ... -> interleave back
-    full = gathered.permute(1, 0, 2).reshape(world * n_pad, 5)[:n_rays]
-    ints = full[:, 3:5].contiguous().view(torch.int32)
-    return full[:, 0:3].contiguous(), ints[:, 0].contiguous(), ints[:, 1].contiguous(), ints[:, 2].contiguous()
+        work = dist.all_gather_into_tensor(flat, local, group=group, async_op=True)
+        return FanGather(work, flat.view(world, n_pad, 5), world, n_pad, n_rays, local)
+    return FanGather(None, local.unsqueeze(0), world, n_pad, n_rays, local)
+
+
+def all_gather_fan(end, n_bott, n_surf, status, n_rays, group=None):
+    """All-gather the local end records and return them in global launch-angle order:
+    ``(end [N,3] float64, n_bott [N], n_surf [N], status [N])`` on every rank."""
+    return start_all_gather_fan(end, n_bott, n_surf, status, n_rays, group=group).finish()
 
 
 def shoot_fan_sharded(compute, y0_all, group=None):
