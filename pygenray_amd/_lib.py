@@ -53,10 +53,16 @@ def build(force=False, verbose=False):
         newest = max(os.path.getmtime(src), os.path.getmtime(hdr))
         if os.path.getmtime(LIB_PATH) >= newest:
             return LIB_PATH
-    cmd = [HIPCC] + HIPCC_FLAGS + ["-o", LIB_PATH, src]
+    tmp = f"{LIB_PATH}.{os.getpid()}.tmp"   # never leave a half-written library behind
+    cmd = [HIPCC] + HIPCC_FLAGS + ["-o", tmp, src]
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, LIB_PATH)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return LIB_PATH
 
 
