@@ -146,6 +146,14 @@ __device__ __forceinline__ double fdiv(double a, double b)
     return a / b;
 #endif
 }
+// 1/b to ~2e-15 (v_rcp_f64 + one Newton step): a SEED for fdiv_y, whose correction step squares
+// the seed's error -- exactly what fdiv() itself does
+__device__ __forceinline__ double frcp_seed(double b)
+{
+    double y = __builtin_amdgcn_rcp(b);
+    double e = fma(-b, y, 1.0);
+    return fma(y, e, y);
+}
 // q = a / b given y ~ 1/b (shared reciprocal)
 __device__ __forceinline__ double fdiv_y(double a, double b, double y)
 {
@@ -506,7 +514,7 @@ struct Ctx {
         if (arg <= 0.0) arg = 1e-30;
 #if PGR_FAST
         double fact = frsqrt(arg);
-        double rc = frcp(c);
+        double rc = frcp_seed(c);  // seeds both quotients below (1/c and, squared, 1/c^2)
         d0 = fdiv_y(fact, c, rc);
         d1 = c * pz * fact;
         d2 = fdiv_y(-fact * cp, c * c, rc * rc);
