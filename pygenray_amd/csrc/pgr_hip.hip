@@ -205,10 +205,10 @@ __device__ __forceinline__ double frsqrt(double x)
     double g = x * y;
     double d = fma(-g, g, x);
     double s = fma(d * 0.5, y, g);   // RN(sqrt x)
-    double r = fma(-s, y, 1.0);      // y ~ 1/s to ~2e-15
-    y = fma(y, r, y);
-    r = fma(-s, y, 1.0);
-    return fma(y, r, y);             // RN(1/s)
+    double r = fma(-s, y, 1.0);      // y ~ 1/s to ~4e-15
+    // one correction: y (1 + r) = 1/s to ~2e-29 relative, rounded once by the fma -- RN(1/s)
+    // unless 1/s lies within ~2^-96 (relative) of a rounding boundary, the same class as fdiv()
+    return fma(y, r, y);
 #else
     return 1 / sqrt(x);
 #endif
