@@ -975,7 +975,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                             // b_j(xi) = sum_k P[j][k] xi^(k+1), in FMAs: no Q = K.T @ P to form (a third
                             // of the work) and a few ulp from SciPy's summation order.  Output samples
                             // never feed back into the integration, so this cannot move a ray.
-                            const double inv_h = frcp(h);
+                            const double inv_h = frcp_seed(h);  // 2e-15 is plenty for xi (no feedback)
 #define PGR_KSUM(k1, k3, k4, k5, k6, k7)                                                          \
     __builtin_fma(k1, b1, __builtin_fma(k3, b3, __builtin_fma(k4, b4, __builtin_fma(k5, b5,      \
                   __builtin_fma(k6, b6, (k7) * b7)))))
