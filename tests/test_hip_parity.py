@@ -189,6 +189,23 @@ def test_nonuniform_grids_generic_search_path(lib):
     gpu_vs_oracle(lib, arrs, y0, 0.0, 80e3, 81, "non-uniform grids")
 
 
+def test_depth_grids_too_large_for_the_lds(lib):
+    """A 0.5 m depth grid (12 001 nodes, 192 KB of {c, cp}) does not fit the 160 KB LDS: the table
+    stays in HBM/L2 -- also for a non-uniform version of the grid, whose depth search (zin + bucket
+    table, 123 KB) still runs from LDS.  Same results as the oracle either way."""
+    z = np.arange(0, 6000.25, 0.5)
+    arrs = munk_arrays(60e3, nr=12, z=z)
+    env = lib.EnvHandle(*arrs)
+    assert env.query(0) and not env.query(3)          # range independent, but no LDS table
+    env.close()
+    y0 = y0_for(oracle, arrs, 1000.0, 0.0, np.linspace(-18, 18, 70))
+    gpu_vs_oracle(lib, arrs, y0, 0.0, 60e3, 31, "0.5 m uniform grid (HBM table)")
+    zs = z * (1 + 1e-5 * z / 6000.0)                  # smoothly stretched: non-uniform
+    arrs2 = munk_arrays(60e3, nr=12, z=zs)
+    gpu_vs_oracle(lib, arrs2, y0_for(oracle, arrs2, 1000.0, 0.0, np.linspace(-18, 18, 70)), 0.0, 60e3, 31,
+                  "0.5 m non-uniform grid (HBM table, LDS depth search)")
+
+
 def test_steps_wider_than_range_cells(lib):
     """The range weights of a step's five stage abscissae are computed together from the cached
     cell, its right neighbour, or cell by cell: a 100 m range grid under loose-tolerance steps
