@@ -117,9 +117,11 @@ int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, double sourc
                          double* p, double* end_state, int32_t* n_bott, int32_t* n_surf,
                          int32_t* status, int32_t* n_steps, int32_t* n_rej, void* stream);
 
-/* Depth-cell search for a non-uniform zin (never changes results): 0 (default) = bucket table + zin
- * in LDS when they fit (the cell of z is bucket[floor((z - z0)/w)] or the next one), 1 = always the
- * binary search of np.searchsorted (REF/integration_processes.py:152-157).  Tests compare the two. */
+/* Depth-cell search for a non-uniform zin (never changes results): 0 (default) = from LDS: the cell
+ * of z is j0 or j0 + 1 with j0 = floor(g(z) - 0.5) from a quadratic index estimate g when zin is
+ * smooth enough (the flat-earth grid is), else j0 = bucket[floor((z - z0)/w)] from a bin table;
+ * 1 = always the binary search of np.searchsorted (REF/integration_processes.py:152-157);
+ * 2 = the bin table even when the quadratic would do.  Tests compare the three. */
 int pgr_set_depth_search(int mode);
 
 /* Tuning knobs (process-wide; per-ray results do not depend on them):

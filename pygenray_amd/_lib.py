@@ -248,7 +248,8 @@ def device_count():
 
 
 def set_depth_search(mode):
-    """0: automatic (bucketed search for non-uniform zin when it fits the LDS), 1: binary search."""
+    """0: automatic (index polynomial or bucket table in LDS for a non-uniform zin), 1: binary search,
+    2: bucket table only."""
     check(load().pgr_set_depth_search(int(mode)))
 
 

@@ -62,6 +62,11 @@ struct EnvDev {
     const unsigned short* zbucket;
     int z_bucket, zb_B;
     double zb_z0, zb_inv_w;
+    // ... or, when zin is smooth enough (the flat-earth grid is), no table at all: a quadratic
+    // g(u) = q0 + u (q1 + u q2), u = (z - zin[0]) / span, with |g(zin[j]) - j| <= 0.45 for every
+    // node and g' > 0 (host verified), so the cell of z is floor(g - 0.5) or the next one
+    int z_quad;
+    double zq_c0, zq_c1, zq_c2, zq_inv_span;
 };
 
 struct FanArgs {
@@ -328,6 +333,7 @@ struct Ctx {
     const unsigned short* lds_zb;   // ZM == 2: LDS copy of zbucket
     const double h_zb_z0, h_zb_inv_w;
     const int h_zb_B;
+    const double h_zq_c0, h_zq_c1, h_zq_c2, h_zq_inv_span;  // ZM == 3
     // per-lane caches: x only moves forward, so the range cell (and the bathymetry cell under
     // the ray) changes once every ~10 km; keep its edges and the reciprocal of its width
     mutable double r_lo, r_hi, r_yden, r_hi2;  // r_hi2: upper edge of the NEXT cell (uniform rin) or r_hi
@@ -341,8 +347,9 @@ struct Ctx {
     __device__ __forceinline__ Ctx(const EnvDev& e_, const double2* l, const double* lz = nullptr,
                                    const unsigned short* lzb = nullptr, const double* lbx = nullptr)
         : e(e_), lds(l), bx(lbx ? lbx : e_.depth_ranges), bd(lbx ? lbx + e_.nb : e_.depths), lds_z(lz),
-          lds_zb(lzb), h_zb_z0(e_.zb_z0), h_zb_inv_w(e_.zb_inv_w),
-          h_zb_B(e_.zb_B), h_inv_dz(e_.inv_dz), h_dz(e_.dz), h_r0(e_.r0), h_dr(e_.dr),
+          lds_zb(lzb), h_zb_z0(e_.zb_z0), h_zb_inv_w(e_.zb_inv_w), h_zb_B(e_.zb_B),
+          h_zq_c0(e_.zq_c0), h_zq_c1(e_.zq_c1), h_zq_c2(e_.zq_c2), h_zq_inv_span(e_.zq_inv_span),
+          h_inv_dz(e_.inv_dz), h_dz(e_.dz), h_r0(e_.r0), h_dr(e_.dr),
           h_b_zmin(e_.b_zmin), h_b_xlo(e_.b_xlo), h_b_xhi(e_.b_xhi), h_zhi_tol(e_.zhi_tol),
           h_zlo_tol(e_.zlo_tol), h_rlo_tol(e_.rlo_tol), h_rhi_tol(e_.rhi_tol),
           h_inv_dr(e_.inv_dr), h_rin(e_.rin), h_nz(e_.nz), h_nr(e_.nr), h_r_uniform(e_.r_uniform)
@@ -416,12 +423,20 @@ struct Ctx {
     {
         Fetch f;
         int j;
-        if (ZM == 2) {
-            // bin -> candidate cell j0 (zin[j0] < every z of the bin <= zin[j0 + 2]); the three
-            // nodes from j0 on are fetched together, then z > zin[j0 + 1] picks the upper cell
-            const double t = (z - h_zb_z0) * h_zb_inv_w;
-            const int k = min(max((int)floor(t), 0), h_zb_B - 1);  // NaN -> 0, like cell_search
-            const int j0 = lds_zb[k];
+        if (ZM == 2 || ZM == 3) {
+            // candidate cell j0 (zin[j0] < z <= zin[j0 + 2]) from the bin table, or from the
+            // quadratic index estimate of a smooth grid; the three nodes from j0 on are fetched
+            // together, then z > zin[j0 + 1] picks the upper cell
+            int j0;
+            if (ZM == 2) {
+                const double t = (z - h_zb_z0) * h_zb_inv_w;
+                const int k = min(max((int)floor(t), 0), h_zb_B - 1);  // NaN -> 0, like cell_search
+                j0 = lds_zb[k];
+            } else {
+                const double u = (z - h_zb_z0) * h_zq_inv_span;
+                const double g = h_zq_c0 + u * (h_zq_c1 + u * h_zq_c2);
+                j0 = min(max((int)floor(g - 0.5), 0), h_nz - 2);      // NaN -> 0
+            }
             const int j2 = min(j0 + 2, h_nz - 1);
             const double za = lds_z[j0], zb = lds_z[j0 + 1], zc = lds_z[j2];
             const bool up = (z > zb) & (j0 + 1 <= h_nz - 2);
@@ -808,7 +823,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     // literals) into constant re-materialisation + SGPR spills inside the step loop
     const EnvDev& env = *env_p;
     extern __shared__ double2 lds_tab[];
-    // LDS layout: [{c, cp}[nz] when LDS_TAB][zin[nz], zbucket[zb_B] when ZM == 2][bathymetry]
+    // LDS layout: [{c, cp}[nz] when LDS_TAB][zin[nz] when ZM >= 2, zbucket[zb_B] when ZM == 2][bathymetry]
     double* const lds_after_tab = (double*)(lds_tab + (LDS_TAB ? env.nz : 0));
     double* const lds_z = lds_after_tab;
     unsigned short* const lds_zb = (unsigned short*)(lds_z + env.nz);
@@ -816,9 +831,9 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
         // stage the single depth profile {c, cp}[nz] into LDS (coalesced 16 B per lane)
         for (int j = threadIdx.x; j < env.nz; j += blockDim.x) lds_tab[j] = env.tab[j];
     }
-    if (ZM == 2) {
+    if (ZM == 2 || ZM == 3) {
         for (int j = threadIdx.x; j < env.nz; j += blockDim.x) lds_z[j] = env.zin[j];
-        for (int j = threadIdx.x; j < env.zb_B; j += blockDim.x) lds_zb[j] = env.zbucket[j];
+        if (ZM == 2) for (int j = threadIdx.x; j < env.zb_B; j += blockDim.x) lds_zb[j] = env.zbucket[j];
     }
     // the bathymetry under a deep ray is looked up every step: {depth_ranges, depths} in LDS too
     double* const lds_bx = (a.bathy_lds_off >= 0) ? (double*)((char*)lds_tab + a.bathy_lds_off) : nullptr;
@@ -1413,7 +1428,7 @@ __global__ void pgr_math_kernel(const double* a, const double* b, int64_t M, dou
 // ====================================================================================
 static thread_local std::string g_err;
 static int g_waves_per_block = 0;
-static int g_depth_search = 0;  // 0: automatic, 1: never use the bucketed search (tests)
+static int g_depth_search = 0;  // 0: automatic, 1: binary search only, 2: bucket table but no index polynomial (tests)
 static int g_park_lanes = 64, g_park_trips = 16;
 static int g_place = 2;  // 0 off, 1 issue priorities only, 2 cost-aware placement + priorities
 
@@ -1477,7 +1492,7 @@ extern "C" int pgr_set_placement(int mode)
 
 extern "C" int pgr_set_depth_search(int mode)
 {
-    if (mode < 0 || mode > 1) return fail("pgr_set_depth_search: 0 = automatic, 1 = no bucket table");
+    if (mode < 0 || mode > 2) return fail("pgr_set_depth_search: 0 = automatic, 1 = binary search, 2 = bucket table (no index polynomial)");
     g_depth_search = mode;
     return 0;
 }
@@ -1680,6 +1695,32 @@ extern "C" int pgr_env_create(pgr_env** out, int device, const double* cin, cons
             }
         }
     }
+    // quadratic index estimate of a smooth non-uniform zin (least squares on (u_j, j), u in [0, 1])
+    d.z_quad = 0; d.zq_c0 = d.zq_c1 = d.zq_c2 = d.zq_inv_span = 0.0;
+    if (!d.z_uniform && nz >= 4 && zin[nz - 1] > zin[0]) {
+        const double span = zin[nz - 1] - zin[0], inv_span = 1.0 / span;
+        long double S0 = 0, S1 = 0, S2 = 0, S3 = 0, S4 = 0, T0 = 0, T1 = 0, T2 = 0;
+        for (int64_t j = 0; j < nz; j++) {
+            const long double u = (long double)((zin[j] - zin[0]) * inv_span), y = (long double)j;
+            S0 += 1; S1 += u; S2 += u * u; S3 += u * u * u; S4 += u * u * u * u;
+            T0 += y; T1 += y * u; T2 += y * u * u;
+        }
+        // normal equations [S0 S1 S2; S1 S2 S3; S2 S3 S4] c = [T0 T1 T2] by Cramer's rule
+        const long double D = S0 * (S2 * S4 - S3 * S3) - S1 * (S1 * S4 - S3 * S2) + S2 * (S1 * S3 - S2 * S2);
+        if (D != 0) {
+            const double c0 = (double)((T0 * (S2 * S4 - S3 * S3) - S1 * (T1 * S4 - S3 * T2) + S2 * (T1 * S3 - S2 * T2)) / D);
+            const double c1 = (double)((S0 * (T1 * S4 - T2 * S3) - T0 * (S1 * S4 - S3 * S2) + S2 * (S1 * T2 - S2 * T1)) / D);
+            const double c2 = (double)((S0 * (S2 * T2 - S3 * T1) - S1 * (S1 * T2 - S2 * T1) + T0 * (S1 * S3 - S2 * S2)) / D);
+            bool ok = (c1 > 0) && (c1 + 2 * c2 > 0);   // g' > 0 on [0, 1]
+            for (int64_t j = 0; j < nz && ok; j++) {
+                volatile double u = (zin[j] - zin[0]) * inv_span;   // the device's own arithmetic
+                volatile double q = c1 + u * c2;
+                volatile double g = c0 + u * q;
+                ok = std::fabs((double)g - (double)j) <= 0.45;
+            }
+            if (ok) { d.z_quad = 1; d.zq_c0 = c0; d.zq_c1 = c1; d.zq_c2 = c2; d.zq_inv_span = inv_span; d.zb_z0 = zin[0]; }
+        }
+    }
     if (upload(e, &e->d, 1, &e->d_dev)) { pgr_env_destroy(e); return -1; }
     *out = e;
     return 0;
@@ -1785,9 +1826,17 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
     const size_t zb_bytes = D.z_bucket ? ((size_t)D.nz * sizeof(double) + (((size_t)D.zb_B * 2 + 15) & ~(size_t)15)) : 0;
     bool lds_tab = env->lds_path != 0;
     int zm = D.z_simple ? 1 : 0;
-    if (!D.z_simple && D.z_bucket && g_depth_search == 0) {
-        if (env->range_indep && tab_bytes + zb_bytes <= env->max_lds) { lds_tab = true; zm = 2; }
-        else if (zb_bytes <= env->max_lds) { lds_tab = false; zm = 2; }
+    const size_t zq_bytes = (size_t)D.nz * sizeof(double);
+    size_t zx_bytes = 0;  // LDS taken by the depth search of the chosen variant
+    if (!D.z_simple && g_depth_search != 1) {
+        if (D.z_quad && g_depth_search == 0) {
+            if (env->range_indep && tab_bytes + zq_bytes <= env->max_lds) { lds_tab = true; zm = 3; zx_bytes = zq_bytes; }
+            else if (zq_bytes <= env->max_lds) { lds_tab = false; zm = 3; zx_bytes = zq_bytes; }
+        }
+        if (zm == 0 && D.z_bucket) {
+            if (env->range_indep && tab_bytes + zb_bytes <= env->max_lds) { lds_tab = true; zm = 2; zx_bytes = zb_bytes; }
+            else if (zb_bytes <= env->max_lds) { lds_tab = false; zm = 2; zx_bytes = zb_bytes; }
+        }
     }
     int wpb, threads;
     int64_t blocks;
@@ -1805,7 +1854,7 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
         blocks = (N + threads - 1) / threads;
         // cost-aware scheduling of the waves (placement, priorities, homogeneous workgroups)
         if (schedule_waves(env, y0, N, waves, wpb, st, a.wave_map, blocks)) return -1;
-        lds = tab_bytes + (zm == 2 ? zb_bytes : 0);
+        lds = tab_bytes + zx_bytes;
     } else {
         wpb = g_waves_per_block ? g_waves_per_block : 4;
         blocks = (waves + wpb - 1) / wpb;
@@ -1818,7 +1867,7 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
             if (m) { a.wave_map = m; blocks = nb2; wpb = W; }
         }
         threads = wpb * 64;
-        lds = (zm == 2) ? zb_bytes : 0;
+        lds = zx_bytes;
     }
     // {depth_ranges, depths} behind everything else in the LDS when 16 nb bytes are left
     a.bathy_lds_off = -1;
@@ -1835,9 +1884,11 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
                            env->d_dev, a);                                                           \
     } while (0)
     if (lds_tab) {
-        if (zm == 1) PGR_LAUNCH(true, 1); else if (zm == 2) PGR_LAUNCH(true, 2); else PGR_LAUNCH(true, 0);
+        if (zm == 1) PGR_LAUNCH(true, 1); else if (zm == 2) PGR_LAUNCH(true, 2);
+        else if (zm == 3) PGR_LAUNCH(true, 3); else PGR_LAUNCH(true, 0);
     } else {
-        if (zm == 1) PGR_LAUNCH(false, 1); else if (zm == 2) PGR_LAUNCH(false, 2); else PGR_LAUNCH(false, 0);
+        if (zm == 1) PGR_LAUNCH(false, 1); else if (zm == 2) PGR_LAUNCH(false, 2);
+        else if (zm == 3) PGR_LAUNCH(false, 3); else PGR_LAUNCH(false, 0);
     }
 #undef PGR_LAUNCH
     HIPCHK(hipGetLastError());

@@ -311,16 +311,17 @@ def test_bucketed_depth_search_equals_binary_search(lib):
         assert not np.allclose(np.diff(arrs[3]), np.diff(arrs[3])[0], rtol=1e-12, atol=0)  # really non-uniform
         y0 = y0_for(oracle, arrs, 400.0, 0.0, np.linspace(-19, 19, 500))
         env = lib.EnvHandle(*arrs)
-        try:
-            a = env.shoot_fan(y0, 0.0, 200e3, 41)
-            lib.set_depth_search(1)
-            b = env.shoot_fan(y0, 0.0, 200e3, 41)
-        finally:
-            lib.set_depth_search(0)
-        for k in ("T", "z", "p", "end"):
-            assert np.array_equal(a[k], b[k], equal_nan=True), k
-        for k in ("status", "n_steps", "n_rej", "n_bott", "n_surf"):
-            assert np.array_equal(a[k], b[k]), k
+        a = env.shoot_fan(y0, 0.0, 200e3, 41)           # automatic: index polynomial or bucket table
+        for mode in (1, 2):                              # binary search; bucket table
+            try:
+                lib.set_depth_search(mode)
+                b = env.shoot_fan(y0, 0.0, 200e3, 41)
+            finally:
+                lib.set_depth_search(0)
+            for k in ("T", "z", "p", "end"):
+                assert np.array_equal(a[k], b[k], equal_nan=True), (mode, k)
+            for k in ("status", "n_steps", "n_rej", "n_bott", "n_surf"):
+                assert np.array_equal(a[k], b[k]), (mode, k)
         # and a depth below / above the grid still clamps to the edge cells (Q4)
         pts = env.eval_points(np.array([10e3, 10e3]), np.array([[0, arrs[3][0] - 5.0, 0], [0, arrs[3][-1] + 5.0, 0]]))
         assert np.all(np.isfinite(pts[:, 3]))
