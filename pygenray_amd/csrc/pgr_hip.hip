@@ -814,7 +814,7 @@ struct SaveGrid {
 // wave ~80 cycles): selects where both sides are cheap, ONE block per kind of rare work, and
 // the memory half of each table look-up issued early with independent work behind it.
 // ------------------------------------------------------------------------------------
-template <bool LDS_TAB, int ZM>
+template <bool LDS_TAB, int ZM, bool SAVE>
 __global__ void __launch_bounds__(512)
 pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
 {
@@ -864,7 +864,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     const double SAFETY = 0.9, MIN_FACTOR = 0.2, MAX_FACTOR = 10;
     const double rtol = a.rtol, atol = a.atol, t_bound = a.x1;
     const int S = a.S;
-    const bool save = (a.T != nullptr);
+    constexpr bool save = SAVE;  // trajectories wanted (a.T != nullptr): the end-state-only kernel carries no sample code
     const bool exact_samples = (a.flags & PGR_EXACT_SAMPLES) != 0;
     const int64_t attempt_limit = 4 * a.max_steps + 4096;  // guard against endless rejection
     // PGR_STORED_SIGN: trajectories leave as pygenray stores them, z -> -z and p -> -p
@@ -1875,13 +1875,17 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
         const size_t at = (lds + 15) & ~(size_t)15, need = (size_t)D.nb * 16;
         if (at + need <= env->max_lds) { a.bathy_lds_off = (int)at; lds = at + need; }
     }
-#define PGR_LAUNCH(LT, ZMV)                                                                          \
+#define PGR_LAUNCH1(LT, ZMV, SV)                                                                     \
     do {                                                                                             \
         if (lds > 64 * 1024)                                                                         \
-            HIPCHK(hipFuncSetAttribute((const void*)pgr_fan_kernel<LT, ZMV>,                         \
+            HIPCHK(hipFuncSetAttribute((const void*)pgr_fan_kernel<LT, ZMV, SV>,                     \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));       \
-        hipLaunchKernelGGL((pgr_fan_kernel<LT, ZMV>), dim3((unsigned)blocks), dim3(threads), lds, st, \
-                           env->d_dev, a);                                                           \
+        hipLaunchKernelGGL((pgr_fan_kernel<LT, ZMV, SV>), dim3((unsigned)blocks), dim3(threads), lds, \
+                           st, env->d_dev, a);                                                       \
+    } while (0)
+#define PGR_LAUNCH(LT, ZMV)                                                                          \
+    do {                                                                                             \
+        if (save) PGR_LAUNCH1(LT, ZMV, true); else PGR_LAUNCH1(LT, ZMV, false);                      \
     } while (0)
     if (lds_tab) {
         if (zm == 1) PGR_LAUNCH(true, 1); else if (zm == 2) PGR_LAUNCH(true, 2);
@@ -1891,6 +1895,7 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
         else if (zm == 3) PGR_LAUNCH(false, 3); else PGR_LAUNCH(false, 0);
     }
 #undef PGR_LAUNCH
+#undef PGR_LAUNCH1
     HIPCHK(hipGetLastError());
     return 0;
 }
