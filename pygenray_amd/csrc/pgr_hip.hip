@@ -814,7 +814,9 @@ struct SaveGrid {
 // wave ~80 cycles): selects where both sides are cheap, ONE block per kind of rare work, and
 // the memory half of each table look-up issued early with independent work behind it.
 // ------------------------------------------------------------------------------------
-template <bool LDS_TAB, int ZM, bool SAVE>
+// SAVE: 0 = end state only (no sample code); 1 = trajectories on a grid that IS np.linspace (recomputed
+// per index, no loads) with the default sample evaluation; 2 = any grid / PGR_EXACT_SAMPLES
+template <bool LDS_TAB, int ZM, int SAVE>
 __global__ void __launch_bounds__(512)
 pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
 {
@@ -864,8 +866,8 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     const double SAFETY = 0.9, MIN_FACTOR = 0.2, MAX_FACTOR = 10;
     const double rtol = a.rtol, atol = a.atol, t_bound = a.x1;
     const int S = a.S;
-    constexpr bool save = SAVE;  // trajectories wanted (a.T != nullptr): the end-state-only kernel carries no sample code
-    const bool exact_samples = (a.flags & PGR_EXACT_SAMPLES) != 0;
+    constexpr bool save = (SAVE != 0);  // trajectories wanted (a.T != nullptr)
+    const bool exact_samples = (SAVE == 2) && (a.flags & PGR_EXACT_SAMPLES) != 0;
     const int64_t attempt_limit = 4 * a.max_steps + 4096;  // guard against endless rejection
     // PGR_STORED_SIGN: trajectories leave as pygenray stores them, z -> -z and p -> -p
     // (REF/ray_objects.py:51-52): a sign-bit xor, exact, and two host passes over 1.6 GB less
@@ -873,7 +875,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
 #define SGN(v) __longlong_as_double(__double_as_longlong(v) ^ (long long)sgn)
     SaveGrid G;
     G.r = a.r_save; G.x0 = a.x0; G.x1 = a.x1; G.step = a.save_step; G.inv_step = a.inv_dsave;
-    G.S = S; G.formula = a.save_formula;
+    G.S = S; G.formula = (SAVE == 1) ? 1 : a.save_formula;
 
     double t = a.x0, y0 = 0, y1 = 0, y2 = 0;
     if (valid) {
@@ -1011,7 +1013,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     }
                             // two copies so that the linspace one holds no load: a load in the loop
                             // makes every iteration wait (vmcnt) for the stores of the one before
-                            if (G.formula) { PGR_SAMPLE_LOOP(((jnext >= S - 1) ? G.x1 : grid_at(G.x0, G.step, jnext))) }
+                            if (SAVE == 1 || G.formula) { PGR_SAMPLE_LOOP(((jnext >= S - 1) ? G.x1 : grid_at(G.x0, G.step, jnext))) }
                             else { PGR_SAMPLE_LOOP(G.r[jnext]) }
 #undef PGR_SAMPLE_LOOP
 #undef PGR_KSUM
@@ -1885,7 +1887,9 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
     } while (0)
 #define PGR_LAUNCH(LT, ZMV)                                                                          \
     do {                                                                                             \
-        if (save) PGR_LAUNCH1(LT, ZMV, true); else PGR_LAUNCH1(LT, ZMV, false);                      \
+        if (!save) PGR_LAUNCH1(LT, ZMV, 0);                                                          \
+        else if (a.save_formula && !(flags & PGR_EXACT_SAMPLES)) PGR_LAUNCH1(LT, ZMV, 1);            \
+        else PGR_LAUNCH1(LT, ZMV, 2);                                                                \
     } while (0)
     if (lds_tab) {
         if (zm == 1) PGR_LAUNCH(true, 1); else if (zm == 2) PGR_LAUNCH(true, 2);

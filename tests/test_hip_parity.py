@@ -328,6 +328,29 @@ def test_bucketed_depth_search_equals_binary_search(lib):
         env.close()
 
 
+def test_save_grid_loaded_or_recomputed(lib):
+    """The save grid is np.linspace: the kernel variant that recomputes r_save[j] per index
+    (PGR_SAVE_LINSPACE) and the one that loads it give the same trajectories bit for bit, and
+    the end-state-only variant the same end states."""
+    import torch
+    from pygenray_amd.device_fan import DeviceFan
+    arrs = munk_arrays(150e3)
+    env = lib.EnvHandle(*arrs)
+    y0 = y0_for(oracle, arrs, 1000.0, 0.0, np.linspace(-20, 20, 700))
+    outs = []
+    for clear in (0, lib.PGR_SAVE_LINSPACE):
+        fan = DeviceFan(env, y0, 0.0, 150e3, 151, save=True, sample_major=True)
+        fan.flags &= ~clear
+        fan.run(); torch.cuda.synchronize()
+        outs.append([t.cpu().numpy() for t in (fan.T, fan.Z, fan.P, fan.end, fan.n_steps, fan.status)])
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b, equal_nan=True)
+    fan = DeviceFan(env, y0, 0.0, 150e3, 151, save=False)
+    fan.run(); torch.cuda.synchronize()
+    assert np.array_equal(fan.end.cpu().numpy(), outs[0][3], equal_nan=True)
+    assert np.array_equal(fan.n_steps.cpu().numpy(), outs[0][4])
+
+
 def test_compact_and_stored_sign_flags(lib):
     """PGR_COMPACT squeezes dropped rays out of the [S][N] trajectories on the device and
     PGR_STORED_SIGN stores -z, -p: both are exactly the host-side post-processing they replace."""
