@@ -14,7 +14,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libpgr_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
+# -disable-machine-licm: the bounce code's asin / sin / pow are inlined polynomials; machine LICM
+# hoists their ~60 fp64 coefficients out of the WHOLE step loop into registers (235-256 VGPRs, 140-170
+# SGPR spills); without it the kernel needs 147-162 VGPRs and 33-92 SGPR spills, and the step loop,
+# whose own constants never fitted anyway, gets up to 3 % faster.  (Three waves per SIMD then fit,
+# but measured slower: 1e6 rays 45.0 vs 42.4 ms, 180 000 rays 13.1 vs 9.8 ms -- a workgroup holds
+# its CU until its last wave ends and the fans are VALU-bound already.)
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-disable-machine-licm"]
 if os.environ.get("PGR_FMA"):      # experiments only: FMA contraction + 2-ulp rsqrt (breaks 1e-8 parity)
     HIPCC_FLAGS += ["-DPGR_FMA", "-ffp-contract=fast"]
 elif os.environ.get("PGR_STRICT"):  # compiler's IEEE divide/sqrt and pow()
