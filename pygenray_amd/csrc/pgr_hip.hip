@@ -709,64 +709,64 @@ struct Dense {
        terms that the NEXT stage does not need sit between the issue of that stage's table read      \
        (fetch) and its first use (rhs_f), fenced by scheduling barriers: ~90 cycles of read latency  \
        per stage that a single in-order wave would otherwise idle through. */                       \
-    const double zs2 = y1 + (f1 * A21) * (H_), ps2 = y2 + (f2 * A21) * (H_);                         \
+    const double zs2 = y1 + (f1 * vA21) * (H_), ps2 = y2 + (f2 * vA21) * (H_);                         \
     const auto ft2 = C.fetch(ir[0], zs2);                                                            \
     PGR_SB();                                                                                        \
-    double a31 = f1 * A31, a32 = f2 * A31, a41 = f1 * A41, a42 = f2 * A41, a51 = f1 * A51,           \
-           a52 = f2 * A51, a61 = f1 * A61, a62 = f2 * A61;                                           \
-    double bs0 = f0 * B1, bs1 = f1 * B1, bs2 = f2 * B1, es0 = f0 * E1, es1 = f1 * E1, es2 = f2 * E1; \
+    double a31 = f1 * vA31, a32 = f2 * vA31, a41 = f1 * vA41, a42 = f2 * vA41, a51 = f1 * vA51,           \
+           a52 = f2 * vA51, a61 = f1 * vA61, a62 = f2 * vA61;                                           \
+    double bs0 = f0 * vB1, bs1 = f1 * vB1, bs2 = f2 * vB1, es0 = f0 * vE1, es1 = f1 * vE1, es2 = f2 * vE1; \
     PGR_SB();                                                                                        \
     C.rhs_f(ft2, wr[0], ps2, k20, k21, k22, cs);                                                     \
-    a31 = a31 + k21 * A32; a32 = a32 + k22 * A32;                                                    \
+    a31 = a31 + k21 * vA32; a32 = a32 + k22 * vA32;                                                    \
     const double zs3 = y1 + a31 * (H_), ps3 = y2 + a32 * (H_);                                       \
     const auto ft3 = C.fetch(ir[1], zs3);                                                            \
     PGR_SB();                                                                                        \
-    a41 = a41 + k21 * A42; a42 = a42 + k22 * A42;                                                    \
-    a51 = a51 + k21 * A52; a52 = a52 + k22 * A52;                                                    \
-    a61 = a61 + k21 * A62; a62 = a62 + k22 * A62;                                                    \
+    a41 = a41 + k21 * vA42; a42 = a42 + k22 * vA42;                                                    \
+    a51 = a51 + k21 * vA52; a52 = a52 + k22 * vA52;                                                    \
+    a61 = a61 + k21 * vA62; a62 = a62 + k22 * vA62;                                                    \
     PGR_SB();                                                                                        \
     C.rhs_f(ft3, wr[1], ps3, k30, k31, k32, cs);                                                     \
-    a41 = a41 + k31 * A43; a42 = a42 + k32 * A43;                                                    \
+    a41 = a41 + k31 * vA43; a42 = a42 + k32 * vA43;                                                    \
     const double zs4 = y1 + a41 * (H_), ps4 = y2 + a42 * (H_);                                       \
     const auto ft4 = C.fetch(ir[2], zs4);                                                            \
     PGR_SB();                                                                                        \
-    a51 = a51 + k31 * A53; a52 = a52 + k32 * A53;                                                    \
-    a61 = a61 + k31 * A63; a62 = a62 + k32 * A63;                                                    \
-    bs0 = bs0 + k30 * B3; bs1 = bs1 + k31 * B3; bs2 = bs2 + k32 * B3;                                \
-    es0 = es0 + k30 * E3; es1 = es1 + k31 * E3; es2 = es2 + k32 * E3;                                \
+    a51 = a51 + k31 * vA53; a52 = a52 + k32 * vA53;                                                    \
+    a61 = a61 + k31 * vA63; a62 = a62 + k32 * vA63;                                                    \
+    bs0 = bs0 + k30 * vB3; bs1 = bs1 + k31 * vB3; bs2 = bs2 + k32 * vB3;                                \
+    es0 = es0 + k30 * vE3; es1 = es1 + k31 * vE3; es2 = es2 + k32 * vE3;                                \
     PGR_SB();                                                                                        \
     C.rhs_f(ft4, wr[2], ps4, k40, k41, k42, cs);                                                     \
-    a51 = a51 + k41 * A54; a52 = a52 + k42 * A54;                                                    \
+    a51 = a51 + k41 * vA54; a52 = a52 + k42 * vA54;                                                    \
     const double zs5 = y1 + a51 * (H_), ps5 = y2 + a52 * (H_);                                       \
     const auto ft5 = C.fetch(ir[3], zs5);                                                            \
     PGR_SB();                                                                                        \
-    a61 = a61 + k41 * A64; a62 = a62 + k42 * A64;                                                    \
-    bs0 = bs0 + k40 * B4; bs1 = bs1 + k41 * B4; bs2 = bs2 + k42 * B4;                                \
-    es0 = es0 + k40 * E4; es1 = es1 + k41 * E4; es2 = es2 + k42 * E4;                                \
+    a61 = a61 + k41 * vA64; a62 = a62 + k42 * vA64;                                                    \
+    bs0 = bs0 + k40 * vB4; bs1 = bs1 + k41 * vB4; bs2 = bs2 + k42 * vB4;                                \
+    es0 = es0 + k40 * vE4; es1 = es1 + k41 * vE4; es2 = es2 + k42 * vE4;                                \
     PGR_SB();                                                                                        \
     C.rhs_f(ft5, wr[3], ps5, k50, k51, k52, cs);                                                     \
-    a61 = a61 + k51 * A65; a62 = a62 + k52 * A65;                                                    \
+    a61 = a61 + k51 * vA65; a62 = a62 + k52 * vA65;                                                    \
     const double zs6 = y1 + a61 * (H_), ps6 = y2 + a62 * (H_);                                       \
     const auto ft6 = C.fetch(ir[4], zs6);                                                            \
     PGR_SB();                                                                                        \
-    bs0 = bs0 + k50 * B5; bs1 = bs1 + k51 * B5; bs2 = bs2 + k52 * B5;                                \
-    es0 = es0 + k50 * E5; es1 = es1 + k51 * E5; es2 = es2 + k52 * E5;                                \
+    bs0 = bs0 + k50 * vB5; bs1 = bs1 + k51 * vB5; bs2 = bs2 + k52 * vB5;                                \
+    es0 = es0 + k50 * vE5; es1 = es1 + k51 * vE5; es2 = es2 + k52 * vE5;                                \
     PGR_SB();                                                                                        \
     C.rhs_f(ft6, wr[4], ps6, k60, k61, k62, cs);                                                     \
     /* y_new = y + h * (K[:-1].T @ B)   (B[1] = 0) */                                                \
-    bs1 = bs1 + k61 * B6; bs2 = bs2 + k62 * B6;                                                      \
+    bs1 = bs1 + k61 * vB6; bs2 = bs2 + k62 * vB6;                                                      \
     const double n1 = y1 + (H_) * bs1, n2 = y2 + (H_) * bs2;                                         \
     /* f_new at t + h: the stage-6 abscissa */                                                       \
     const auto ft7 = C.fetch(ir[4], n1);                                                             \
     PGR_SB();                                                                                        \
-    bs0 = bs0 + k60 * B6;                                                                            \
+    bs0 = bs0 + k60 * vB6;                                                                            \
     const double n0 = y0 + (H_) * bs0;                                                               \
-    es0 = es0 + k60 * E6; es1 = es1 + k61 * E6; es2 = es2 + k62 * E6;                                \
+    es0 = es0 + k60 * vE6; es1 = es1 + k61 * vE6; es2 = es2 + k62 * vE6;                                \
     PGR_SB();                                                                                        \
     double c_new;                                                                                    \
     C.rhs_f(ft7, wr[4], n2, k70, k71, k72, c_new);                                                   \
     /* K.T @ E complete (E[1] = 0), SCIPY/rk.py:106-110 */                                           \
-    es0 = es0 + k70 * E7; es1 = es1 + k71 * E7; es2 = es2 + k72 * E7
+    es0 = es0 + k70 * vE7; es1 = es1 + k71 * vE7; es2 = es2 + k72 * vE7
 
 // the save grid np.linspace(x0, x1, S): either recomputed per index exactly as NumPy does
 // (arange(S) * step + start, last point forced to x1 -- verified bitwise on the host) or loaded
@@ -901,6 +901,38 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
 #define Zp (a.Z + out_off)
 #define Pp (a.P + out_off)
 
+    // The 26 tableau coefficients of the stage sums live in VGPRs for the whole kernel (the kernel
+    // needs ~155 of its 256 VGPRs otherwise): an fp64 literal cannot be an inline operand, so each use
+    // cost two s_mov_b32 -- 61 SALU instructions per attempt that a lone wave cannot overlap.  The
+    // empty asm hides the value from constant propagation.
+#define PGR_VCONST(n) double v##n = n; asm volatile("" : "+v"(v##n))
+    PGR_VCONST(A21);
+    PGR_VCONST(A31);
+    PGR_VCONST(A32);
+    PGR_VCONST(A41);
+    PGR_VCONST(A42);
+    PGR_VCONST(A43);
+    PGR_VCONST(A51);
+    PGR_VCONST(A52);
+    PGR_VCONST(A53);
+    PGR_VCONST(A54);
+    PGR_VCONST(A61);
+    PGR_VCONST(A62);
+    PGR_VCONST(A63);
+    PGR_VCONST(A64);
+    PGR_VCONST(A65);
+    PGR_VCONST(B1);
+    PGR_VCONST(B3);
+    PGR_VCONST(B4);
+    PGR_VCONST(B5);
+    PGR_VCONST(B6);
+    PGR_VCONST(E1);
+    PGR_VCONST(E3);
+    PGR_VCONST(E4);
+    PGR_VCONST(E5);
+    PGR_VCONST(E6);
+    PGR_VCONST(E7);
+#undef PGR_VCONST
     // One trip = one step attempt of every stepping lane, THEN the gate that decides whether the
     // wave services its parked lanes.  (The first trip only runs the gate: every lane starts with
     // need_init.)  The step comes first so that the common path -- nobody parked -- is the loop's
