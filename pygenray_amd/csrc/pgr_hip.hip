@@ -933,6 +933,27 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     PGR_VCONST(E6);
     PGR_VCONST(E7);
 #undef PGR_VCONST
+    // ... and, in the kernels that save trajectories, the 18 coefficients of the stage-major sample form
+#define PGR_VCONST_IF(c, n) double v##n = n; if (c) asm volatile("" : "+v"(v##n))
+    PGR_VCONST_IF(SAVE != 0, P11);
+    PGR_VCONST_IF(SAVE != 0, P12);
+    PGR_VCONST_IF(SAVE != 0, P13);
+    PGR_VCONST_IF(SAVE != 0, P31);
+    PGR_VCONST_IF(SAVE != 0, P32);
+    PGR_VCONST_IF(SAVE != 0, P33);
+    PGR_VCONST_IF(SAVE != 0, P41);
+    PGR_VCONST_IF(SAVE != 0, P42);
+    PGR_VCONST_IF(SAVE != 0, P43);
+    PGR_VCONST_IF(SAVE != 0, P51);
+    PGR_VCONST_IF(SAVE != 0, P52);
+    PGR_VCONST_IF(SAVE != 0, P53);
+    PGR_VCONST_IF(SAVE != 0, P61);
+    PGR_VCONST_IF(SAVE != 0, P62);
+    PGR_VCONST_IF(SAVE != 0, P63);
+    PGR_VCONST_IF(SAVE != 0, P71);
+    PGR_VCONST_IF(SAVE != 0, P72);
+    PGR_VCONST_IF(SAVE != 0, P73);
+#undef PGR_VCONST_IF
     // One trip = one step attempt of every stepping lane, THEN the gate that decides whether the
     // wave services its parked lanes.  (The first trip only runs the gate: every lane starts with
     // need_init.)  The step comes first so that the common path -- nobody parked -- is the loop's
@@ -1031,12 +1052,12 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
 #define PGR_SAMPLE_LOOP(NEXT)                                                                     \
     while (jnext < S - 1 && rnext <= t_new) {                                                     \
         const double xi = (rnext - t) * inv_h, x2 = xi * xi;                                      \
-        const double b1 = xi * __builtin_fma(xi, __builtin_fma(xi, __builtin_fma(xi, P13, P12), P11), P10); \
-        const double b3 = x2 * __builtin_fma(xi, __builtin_fma(xi, P33, P32), P31);               \
-        const double b4 = x2 * __builtin_fma(xi, __builtin_fma(xi, P43, P42), P41);               \
-        const double b5 = x2 * __builtin_fma(xi, __builtin_fma(xi, P53, P52), P51);               \
-        const double b6 = x2 * __builtin_fma(xi, __builtin_fma(xi, P63, P62), P61);               \
-        const double b7 = x2 * __builtin_fma(xi, __builtin_fma(xi, P73, P72), P71);               \
+        const double b1 = xi * __builtin_fma(xi, __builtin_fma(xi, __builtin_fma(xi, vP13, vP12), vP11), P10); \
+        const double b3 = x2 * __builtin_fma(xi, __builtin_fma(xi, vP33, vP32), vP31);               \
+        const double b4 = x2 * __builtin_fma(xi, __builtin_fma(xi, vP43, vP42), vP41);               \
+        const double b5 = x2 * __builtin_fma(xi, __builtin_fma(xi, vP53, vP52), vP51);               \
+        const double b6 = x2 * __builtin_fma(xi, __builtin_fma(xi, vP63, vP62), vP61);               \
+        const double b7 = x2 * __builtin_fma(xi, __builtin_fma(xi, vP73, vP72), vP71);               \
         Tp[(int64_t)jnext * a.stride_smp] = __builtin_fma(h, PGR_KSUM(f0, k30, k40, k50, k60, k70), y0); \
         Zp[(int64_t)jnext * a.stride_smp] = SGN(__builtin_fma(h, PGR_KSUM(f1, k31, k41, k51, k61, k71), y1)); \
         Pp[(int64_t)jnext * a.stride_smp] = SGN(__builtin_fma(h, PGR_KSUM(f2, k32, k42, k52, k62, k72), y2)); \
