@@ -342,6 +342,8 @@ struct Ctx {
     // descriptor is read from memory where it is needed)
     const double h_inv_dz, h_dz, h_r0, h_dr, h_inv_dr;
     const double h_b_zmin, h_b_xlo, h_b_xhi, h_zhi_tol, h_zlo_tol, h_rlo_tol, h_rhi_tol;  // events()
+    const double h_b0, h_db, h_inv_db;  // bathy()
+    const int h_nb, h_b_uniform;
     const double* const h_rin;
     const int h_nz, h_nr, h_r_uniform;
     __device__ __forceinline__ Ctx(const EnvDev& e_, const double2* l, const double* lz = nullptr,
@@ -351,7 +353,8 @@ struct Ctx {
           h_zq_c0(e_.zq_c0), h_zq_c1(e_.zq_c1), h_zq_c2(e_.zq_c2), h_zq_inv_span(e_.zq_inv_span),
           h_inv_dz(e_.inv_dz), h_dz(e_.dz), h_r0(e_.r0), h_dr(e_.dr),
           h_b_zmin(e_.b_zmin), h_b_xlo(e_.b_xlo), h_b_xhi(e_.b_xhi), h_zhi_tol(e_.zhi_tol),
-          h_zlo_tol(e_.zlo_tol), h_rlo_tol(e_.rlo_tol), h_rhi_tol(e_.rhi_tol),
+          h_zlo_tol(e_.zlo_tol), h_rlo_tol(e_.rlo_tol), h_rhi_tol(e_.rhi_tol), h_b0(e_.b0), h_db(e_.db),
+          h_inv_db(e_.inv_db), h_nb(e_.nb), h_b_uniform(e_.b_uniform),
           h_inv_dr(e_.inv_dr), h_rin(e_.rin), h_nz(e_.nz), h_nr(e_.nr), h_r_uniform(e_.r_uniform)
     {
         r_lo = 1.0; r_hi = 0.0; r_yden = 1.0; r_hi2 = 0.0; r_i = 0;  // empty interval: first use refills
@@ -494,12 +497,12 @@ struct Ctx {
     {
         int i;
         double xi, xi1;
-        if (e.b_uniform) {
-            i = cell_uniform(x, e.b0, e.db, e.inv_db, e.nb);
-            xi = grid_at(e.b0, e.db, i);
-            xi1 = grid_at(e.b0, e.db, i + 1);
+        if (h_b_uniform) {
+            i = cell_uniform(x, h_b0, h_db, h_inv_db, h_nb);
+            xi = grid_at(h_b0, h_db, i);
+            xi1 = grid_at(h_b0, h_db, i + 1);
         } else {
-            i = cell_search(x, bx, e.nb);
+            i = cell_search(x, bx, h_nb);
             xi = bx[i];
             xi1 = bx[i + 1];
         }
