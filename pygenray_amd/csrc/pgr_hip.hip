@@ -344,6 +344,10 @@ struct Ctx {
     const double h_b_zmin, h_b_xlo, h_b_xhi, h_zhi_tol, h_zlo_tol, h_rlo_tol, h_rhi_tol;  // events()
     const double h_b0, h_db, h_inv_db;  // bathy()
     const int h_nb, h_b_uniform;
+    const double2* const h_tab;  // HBM table variant
+    const int h_row_stride, h_z_uniform, h_z_pow2;
+    const double h_z0;
+    const double* const h_zin;
     const double* const h_rin;
     const int h_nz, h_nr, h_r_uniform;
     __device__ __forceinline__ Ctx(const EnvDev& e_, const double2* l, const double* lz = nullptr,
@@ -354,7 +358,9 @@ struct Ctx {
           h_inv_dz(e_.inv_dz), h_dz(e_.dz), h_r0(e_.r0), h_dr(e_.dr),
           h_b_zmin(e_.b_zmin), h_b_xlo(e_.b_xlo), h_b_xhi(e_.b_xhi), h_zhi_tol(e_.zhi_tol),
           h_zlo_tol(e_.zlo_tol), h_rlo_tol(e_.rlo_tol), h_rhi_tol(e_.rhi_tol), h_b0(e_.b0), h_db(e_.db),
-          h_inv_db(e_.inv_db), h_nb(e_.nb), h_b_uniform(e_.b_uniform),
+          h_inv_db(e_.inv_db), h_nb(e_.nb), h_b_uniform(e_.b_uniform), h_tab(e_.tab),
+          h_row_stride(e_.row_stride), h_z_uniform(e_.z_uniform), h_z_pow2(e_.z_pow2), h_z0(e_.z0),
+          h_zin(e_.zin),
           h_inv_dr(e_.inv_dr), h_rin(e_.rin), h_nz(e_.nz), h_nr(e_.nr), h_r_uniform(e_.r_uniform)
     {
         r_lo = 1.0; r_hi = 0.0; r_yden = 1.0; r_hi2 = 0.0; r_i = 0;  // empty interval: first use refills
@@ -363,14 +369,14 @@ struct Ctx {
     __device__ __forceinline__ int cell_z(double z, double& zj, double& zj1) const
     {
         int j;
-        if (e.z_uniform) {
-            j = cell_uniform(z, e.z0, e.dz, e.inv_dz, e.nz);
-            zj = grid_at(e.z0, e.dz, j);
-            zj1 = grid_at(e.z0, e.dz, j + 1);
+        if (h_z_uniform) {
+            j = cell_uniform(z, h_z0, h_dz, h_inv_dz, h_nz);
+            zj = grid_at(h_z0, h_dz, j);
+            zj1 = grid_at(h_z0, h_dz, j + 1);
         } else {
-            j = cell_search(z, e.zin, e.nz);
-            zj = e.zin[j];
-            zj1 = e.zin[j + 1];
+            j = cell_search(z, h_zin, h_nz);
+            zj = h_zin[j];
+            zj1 = h_zin[j + 1];
         }
         return j;
     }
@@ -462,7 +468,7 @@ struct Ctx {
             double zj, zj1;
             j = cell_z(z, zj, zj1);
             // every cell exactly dz wide and dz a power of two: the division is an exact scaling
-            f.wy = e.z_pow2 ? (z - zj) * e.inv_dz : fdiv(z - zj, zj1 - zj);
+            f.wy = h_z_pow2 ? (z - zj) * h_inv_dz : fdiv(z - zj, zj1 - zj);
         }
         if (LDS_TAB) {
             f.v00 = lds[j];
@@ -470,11 +476,11 @@ struct Ctx {
             f.v10 = f.v00;  // range independent: rows are bitwise identical
             f.v11 = f.v01;
         } else {
-            const double2* row = e.tab + (size_t)i * e.row_stride + j;
+            const double2* row = h_tab + (size_t)i * h_row_stride + j;
             f.v00 = row[0];
             f.v01 = row[1];
-            f.v10 = row[e.row_stride];
-            f.v11 = row[e.row_stride + 1];
+            f.v10 = row[h_row_stride];
+            f.v11 = row[h_row_stride + 1];
         }
         return f;
     }
