@@ -223,7 +223,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_gb_per_launch": traffic_gb,
                          "algorithmic_gb_per_launch": local_steps * b_alg / 1e9,
-                         "kernel": "pgr_fan_kernel<LDS table>", "kernel_ms": kern_ms,
+                         "kernel": f"pgr_fan_kernel<true, 1, {1 if save else 0}> (table in LDS, zin = j dz, "
+                                   f"{'linspace save grid' if save else 'end state only'})", "kernel_ms": kern_ms,
                          "bytes_per_ray_step": b_alg,
                          "note": "algorithmic bytes per SURVEY 8(d); the stepper keeps state in "
                                  "VGPRs and the SSP table in LDS, so it is fp64-VALU bound, not HBM bound"},
