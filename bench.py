@@ -223,7 +223,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_gb_per_launch": traffic_gb,
                          "algorithmic_gb_per_launch": local_steps * b_alg / 1e9,
-                         "kernel": f"pgr_fan_kernel<true, 1, {1 if save else 0}> (table in LDS, zin = j dz, "
+                         "kernel": f"pgr_fan_kernel<true, 4, {1 if save else 0}> (table in LDS, zin = j * 1 m, "
                                    f"{'linspace save grid' if save else 'end state only'})", "kernel_ms": kern_ms,
                          "bytes_per_ray_step": b_alg,
                          "note": "algorithmic bytes per SURVEY 8(d); the stepper keeps state in "

@@ -324,7 +324,7 @@ __device__ __forceinline__ int cell_search(double q, const double* __restrict__ 
 // through L2 (the reference's default flat-earth grid: 36 -> 11 ms per 1e5-ray fan).
 template <bool LDS_TAB, int ZM>
 struct Ctx {
-    static constexpr bool ZS = (ZM == 1);
+    static constexpr bool ZS = (ZM == 1 || ZM == 4);  // ZM == 4: ZS with dz == 1.0 (np.arange(0, 6000, 1)): no scaling at all
     const EnvDev& e;
     const double2* lds;  // LDS copy of the (single) depth profile when LDS_TAB
     const double* bx;               // depth_ranges and depths: LDS copies when they fit, else HBM
@@ -460,10 +460,11 @@ struct Ctx {
                 return f;
             }
         } else if (ZS) {
-            double t = z * h_inv_dz;                     // exact
+            const double t = (ZM == 4) ? z : z * h_inv_dz;  // exact
             // v_cvt_i32_f64 saturates and maps NaN to 0: no clamp needed before the conversion
             j = min(max((int)ceil(t) - 1, 0), h_nz - 2);
-            f.wy = (z - (double)j * h_dz) * h_inv_dz;    // (z - zin[j]) / dz, exact scaling
+            // (z - zin[j]) / dz, an exact scaling (by 1 when ZM == 4: the same bits without the multiplies)
+            f.wy = (ZM == 4) ? (z - (double)j) : (z - (double)j * h_dz) * h_inv_dz;
         } else {
             double zj, zj1;
             j = cell_z(z, zj, zj1);
@@ -1897,7 +1898,7 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
     const size_t tab_bytes = (size_t)D.nz * sizeof(double2);
     const size_t zb_bytes = D.z_bucket ? ((size_t)D.nz * sizeof(double) + (((size_t)D.zb_B * 2 + 15) & ~(size_t)15)) : 0;
     bool lds_tab = env->lds_path != 0;
-    int zm = D.z_simple ? 1 : 0;
+    int zm = D.z_simple ? ((D.dz == 1.0) ? 4 : 1) : 0;
     const size_t zq_bytes = (size_t)D.nz * sizeof(double);
     size_t zx_bytes = 0;  // LDS taken by the depth search of the chosen variant
     if (!D.z_simple && g_depth_search != 1) {
@@ -1963,10 +1964,10 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
     } while (0)
     if (lds_tab) {
         if (zm == 1) PGR_LAUNCH(true, 1); else if (zm == 2) PGR_LAUNCH(true, 2);
-        else if (zm == 3) PGR_LAUNCH(true, 3); else PGR_LAUNCH(true, 0);
+        else if (zm == 3) PGR_LAUNCH(true, 3); else if (zm == 4) PGR_LAUNCH(true, 4); else PGR_LAUNCH(true, 0);
     } else {
         if (zm == 1) PGR_LAUNCH(false, 1); else if (zm == 2) PGR_LAUNCH(false, 2);
-        else if (zm == 3) PGR_LAUNCH(false, 3); else PGR_LAUNCH(false, 0);
+        else if (zm == 3) PGR_LAUNCH(false, 3); else if (zm == 4) PGR_LAUNCH(false, 4); else PGR_LAUNCH(false, 0);
     }
 #undef PGR_LAUNCH
 #undef PGR_LAUNCH1

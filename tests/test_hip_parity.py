@@ -189,6 +189,19 @@ def test_nonuniform_grids_generic_search_path(lib):
     gpu_vs_oracle(lib, arrs, y0, 0.0, 80e3, 81, "non-uniform grids")
 
 
+def test_power_of_two_depth_steps_other_than_one(lib):
+    """zin = j dz with dz a power of two takes the index-by-scaling path; dz = 1 m (the reference's
+    default grid) has its own kernel instance without the scalings.  dz = 2 m and 0.25 m here."""
+    for dz in (2.0, 0.25):
+        z = np.arange(0, 1500.0 + dz / 2, dz)
+        arrs = munk_arrays(40e3, nr=9, z=z, bathy=1400.0)
+        env = lib.EnvHandle(*arrs)
+        assert env.query(0) and env.query(1) and env.query(3)
+        env.close()
+        y0 = y0_for(oracle, arrs, 700.0, 0.0, np.linspace(-12, 12, 66))
+        gpu_vs_oracle(lib, arrs, y0, 0.0, 40e3, 33, f"dz = {dz} m")
+
+
 def test_depth_grids_too_large_for_the_lds(lib):
     """A 0.5 m depth grid (12 001 nodes, 192 KB of {c, cp}) does not fit the 160 KB LDS: the table
     stays in HBM/L2 -- also for a non-uniform version of the grid, whose depth search (zin + bucket
