@@ -572,3 +572,24 @@ def test_wave_scheduler_is_a_pure_permutation(lib):
     lib.set_placement(2)
     got = env2.shoot_fan(y0, 0.0, 60e3, 1, save=False)
     assert np.array_equal(got["end"], ref["end"], equal_nan=True) and np.array_equal(got["status"], ref["status"])
+
+
+def test_plain_c_example_runs(lib, tmp_path):
+    """examples/shoot_fan.c (C99, no Python, no torch) drives the library and gets the oracle's rays."""
+    import re
+    import subprocess
+    from test_host import _build_c_example
+    exe = _build_c_example(tmp_path)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    rows = re.findall(r"ray\s+(\d+): status (\d+), T = ([0-9.]+) s, z = ([-0-9.]+) m, (\d+) steps", out.stdout)
+    assert len(rows) == 8
+    arrs = munk_arrays(100e3, nr=20)
+    th = -15.0 + 30.0 * np.arange(64) / 63
+    y0 = y0_for(oracle, arrs, 1000.0, 0.0, th)
+    o = oracle.shoot_fan(*arrs, y0, 0.0, 100e3, 2)
+    for k, st, T, z, nsteps in rows:
+        k = int(k)
+        assert int(st) == o["status"][k] == 0
+        assert abs(float(T) - o["T"][k, -1]) < 1e-8 * 70 and abs(float(z) - o["z"][k, -1]) < 2e-5
+        assert abs(int(nsteps) - o["n_steps"][k]) <= 2

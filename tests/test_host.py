@@ -279,3 +279,23 @@ def test_pack_and_interleave_single_process():
     e2, b2, s2, st2 = all_gather_fan(end, nb, nb * 2, nb * 0, 5)
     assert torch.equal(e2, end) and torch.equal(b2, nb) and torch.equal(s2, nb * 2)
     assert list(shard_indices(10, 1, 4)) == [1, 5, 9]
+
+
+def _build_c_example(tmp_path):
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, "pygenray_amd", "csrc")
+    if not os.path.exists(os.path.join(lib_dir, "libpgr_hip.so")) or shutil.which("gcc") is None:
+        pytest.skip("libpgr_hip.so or gcc not available")
+    exe = os.path.join(str(tmp_path), "shoot_fan")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "examples", "shoot_fan.c"), "-o", exe, "-L" + lib_dir, "-lpgr_hip",
+                           "-lm", "-Wl,-rpath," + lib_dir])
+    return exe
+
+
+def test_header_is_plain_c_and_example_links(tmp_path):
+    """include/pgr.h is valid C99 and every entry point the plain-C example uses resolves against
+    libpgr_hip.so (compile + link only: no GPU needed)."""
+    assert os.path.exists(_build_c_example(tmp_path))
