@@ -1,5 +1,6 @@
 """Distribution of HIP-vs-oracle end-state deviations on the headline fan (every k-th ray),
-next to the oracle's own spread under 1-ulp perturbations.  usage: parity_stats.py [lib.so] [stride]"""
+next to the oracle's own spread under 1-ulp perturbations.
+usage: parity_stats.py [lib.so|-] [stride] [exact]   (exact: PGR_EXACT_BISECTION, SciPy's own event bisection)"""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -14,11 +15,12 @@ theta = np.linspace(-20, 20, 100_000)[::stride]
 y0 = y0_for(oracle, arrs, 1000.0, 0.0, -theta)
 o = oracle.shoot_fan(*arrs, y0, 0.0, 1000e3, 2)
 noise = oracle_selfnoise(oracle, arrs, y0, 0.0, 1000e3, 2)
-g = _lib.EnvHandle(*arrs).shoot_fan(y0, 0.0, 1000e3, 2)
+exact = len(sys.argv) > 3 and sys.argv[3] == "exact"
+g = _lib.EnvHandle(*arrs).shoot_fan(y0, 0.0, 1000e3, 2, exact_bisection=exact)
 ok = (o["status"] == 0) & (g["status"] == 0)
 quiet = ((o["n_bott"] + o["n_surf"]) == 0) & ok
 bnc = ok & ~quiet
-print("lib:", _lib.LIB_PATH, " rays:", len(theta), "status equal:", np.array_equal(o["status"], g["status"]),
+print("lib:", _lib.LIB_PATH, "exact bisection:", exact, " rays:", len(theta), "status equal:", np.array_equal(o["status"], g["status"]),
       "bounce counts equal:", np.array_equal(o["n_bott"][ok], g["n_bott"][ok]) and np.array_equal(o["n_surf"][ok], g["n_surf"][ok]),
       "n_steps equal frac:", np.mean(o["n_steps"][ok] == g["n_steps"][ok]))
 def q(x): return " ".join(f"{v:.1e}" for v in np.quantile(x, [0.5, 0.9, 0.99, 1.0]))
