@@ -299,3 +299,22 @@ def test_header_is_plain_c_and_example_links(tmp_path):
     """include/pgr.h is valid C99 and every entry point the plain-C example uses resolves against
     libpgr_hip.so (compile + link only: no GPU needed)."""
     assert os.path.exists(_build_c_example(tmp_path))
+
+
+def test_committed_bench_line_and_profiles_are_well_formed():
+    """profiles/ carries the round's rocprofv3 summaries and the bench line they belong to."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = json.load(open(os.path.join(root, "profiles", "r01_bench_line.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["dtype"] == "f64" and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert d["cpu_baseline"]["kind"] in ("port", "reference") and d["cpu_baseline"]["cores"] >= 1
+    stats = open(os.path.join(root, "profiles", "r01_kernel_stats.csv")).read()
+    assert "pgr_fan_kernel" in stats
+    tr = json.load(open(os.path.join(root, "profiles", "r01_traffic.json")))
+    assert tr["sample"]["hbm_gb_per_launch"] > 0
