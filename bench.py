@@ -114,7 +114,7 @@ def main():
     import torch.distributed as dist
     from pygenray_amd import _lib
     from pygenray_amd.device_fan import DeviceFan, fan_y0
-    from pygenray_amd.distributed import shard_indices, all_gather_fan, start_all_gather_fan
+    from pygenray_amd.distributed import shard_indices, all_gather_fan, start_all_gather_records
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -140,12 +140,14 @@ def main():
     idx = shard_indices(n_global, rank, world)
     y0 = fan_y0(arrs, SOURCE_DEPTH, 0.0, -theta[idx])  # ODE angle = -user (>= 70-ray branch)
     save = not args.no_save
-    fan = DeviceFan(env, y0, 0.0, RANGE_M, S_SAVE, save=save, sample_major=(args.layout == "sample"))
+    # N > 1: the kernel writes the 40-byte end records of the all-gather itself (PGR_PACKED_END)
+    fan = DeviceFan(env, y0, 0.0, RANGE_M, S_SAVE, save=save, sample_major=(args.layout == "sample"),
+                    packed_end=use_dist, n_pad=(n_global + world - 1) // world)
 
     def step():
         fan.run()
         if use_dist:
-            return all_gather_fan(fan.end, fan.n_bott, fan.n_surf, fan.status, n_global)
+            return start_all_gather_records(fan.records, n_global).finish()
         return None
 
     def fence():
@@ -168,7 +170,7 @@ def main():
         if use_dist:
             # the end records of pass k travel (RCCL stream) while pass k+1 integrates; every
             # gathered fan is reassembled in launch-angle order before the clock stops
-            started = start_all_gather_fan(fan.end, fan.n_bott, fan.n_surf, fan.status, n_global)
+            started = start_all_gather_records(fan.records, n_global)
             if pending is not None:
                 pending.finish()
             pending = started

@@ -70,6 +70,11 @@ extern "C" {
                                       of rays with status 0, in launch order, at the start of the caller's
                                       [S][N] buffers; the per-ray arrays keep all N entries */
 
+#define PGR_PACKED_END 256u        /* (device entry) end_state is [N][5] doubles: T, z, p, then n_bott,
+                                      n_surf, status and a valid mark (1) as four int32 in the last two
+                                      slots -- the end record the multi-GPU all-gather ships, written by
+                                      the kernel instead of packed afterwards */
+
 typedef struct pgr_env pgr_env; /* opaque: environment tables resident in HBM */
 
 /* Number of visible HIP devices (<0 on error). */

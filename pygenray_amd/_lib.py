@@ -34,6 +34,7 @@ PGR_EXACT_BISECTION = 4
 PGR_EXACT_SAMPLES = 32
 PGR_STORED_SIGN = 64
 PGR_COMPACT = 128
+PGR_PACKED_END = 256
 PGR_SAVE_LINSPACE = 8
 
 RAY_STATUS = {0: "ok", 1: "vertical", 2: "bbox", 3: "backward", 4: "step_too_small",

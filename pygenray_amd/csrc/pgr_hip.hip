@@ -1334,9 +1334,18 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
             }
         }
         if (a.end_state) {
-            a.end_state[3 * ray + 0] = ok ? y0 : nan;
-            a.end_state[3 * ray + 1] = ok ? y1 : nan;
-            a.end_state[3 * ray + 2] = ok ? y2 : nan;
+            if (a.flags & PGR_PACKED_END) {
+                // the 40-byte end record of the multi-GPU all-gather, written in place: T, z, p and
+                // {n_bott, n_surf}, {status, valid = 1} as int32 pairs in two more double slots
+                double* rec = a.end_state + 5 * ray;
+                rec[0] = ok ? y0 : nan; rec[1] = ok ? y1 : nan; rec[2] = ok ? y2 : nan;
+                int* ir = (int*)(rec + 3);
+                ir[0] = nb; ir[1] = ns; ir[2] = status; ir[3] = 1;
+            } else {
+                a.end_state[3 * ray + 0] = ok ? y0 : nan;
+                a.end_state[3 * ray + 1] = ok ? y1 : nan;
+                a.end_state[3 * ray + 2] = ok ? y2 : nan;
+            }
         }
         a.n_bott[ray] = nb;
         a.n_surf[ray] = ns;

@@ -17,7 +17,8 @@ class DeviceFan:
 
     def __init__(self, env_handle, y0, source_range, receiver_range, num_range_save, rtol=1e-9,
                  atol=1e-6, terminate_backwards=True, save=True, sample_major=False,
-                 max_steps=1_000_000, exact_bisection=False, exact_samples=False):
+                 max_steps=1_000_000, exact_bisection=False, exact_samples=False, packed_end=False,
+                 n_pad=None):
         self.env = env_handle
         dev = torch.device("cuda", env_handle.device)
         self.dev = dev
@@ -28,8 +29,8 @@ class DeviceFan:
         self.flags = (_lib.PGR_TERMINATE_BACKWARDS if terminate_backwards else 0) | \
             (_lib.PGR_SAMPLE_MAJOR if sample_major else 0) | _lib.PGR_SAVE_LINSPACE | \
             (_lib.PGR_EXACT_BISECTION if exact_bisection else 0) | \
-            (_lib.PGR_EXACT_SAMPLES if exact_samples else 0)
-        self.save, self.sample_major = save, sample_major
+            (_lib.PGR_EXACT_SAMPLES if exact_samples else 0) | (_lib.PGR_PACKED_END if packed_end else 0)
+        self.save, self.sample_major, self.packed_end = save, sample_major, packed_end
         f64 = dict(dtype=torch.float64, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
         self.y0 = torch.from_numpy(y0).to(dev)
@@ -41,7 +42,14 @@ class DeviceFan:
             self.P = torch.empty(shape, **f64)
         else:
             self.T = self.Z = self.P = None
-        self.end = torch.empty((self.N, 3), **f64)
+        if packed_end:
+            # [n_pad][5] end records (PGR_PACKED_END), ready for the all-gather: rows beyond N stay
+            # zero (valid = 0); `end` is the (N, 3) view of the state columns
+            self.records = torch.zeros((max(int(n_pad or 0), self.N), 5), **f64)
+            self.end = self.records[:self.N, 0:3]
+        else:
+            self.records = None
+            self.end = torch.empty((self.N, 3), **f64)
         self.n_bott = torch.empty(self.N, **i32)
         self.n_surf = torch.empty(self.N, **i32)
         self.status = torch.empty(self.N, **i32)
@@ -54,7 +62,8 @@ class DeviceFan:
         stream = torch.cuda.current_stream(self.dev).cuda_stream
         self.env.shoot_fan_device(ptr(self.y0), self.N, self.x0, self.x1, ptr(self.r_save), self.S,
                                   self.rtol, self.atol, self.flags, self.max_steps, ptr(self.T),
-                                  ptr(self.Z), ptr(self.P), ptr(self.end), ptr(self.n_bott),
+                                  ptr(self.Z), ptr(self.P),
+                                  ptr(self.records if self.packed_end else self.end), ptr(self.n_bott),
                                   ptr(self.n_surf), ptr(self.status), ptr(self.n_steps),
                                   ptr(self.n_rej), stream)
 

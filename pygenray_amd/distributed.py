@@ -52,6 +52,21 @@ class FanGather:
                 ints[:, 2].contiguous())
 
 
+def start_all_gather_records(records, n_rays, group=None):
+    """The same for end records the kernel already packed (``DeviceFan(packed_end=True,
+    n_pad=ceil(n_rays / world))``): the send buffer is cloned (one copy kernel) so that the next
+    fan may overwrite ``records`` while they travel."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    n_pad = (n_rays + world - 1) // world
+    assert records.shape == (n_pad, 5), (tuple(records.shape), n_pad)
+    local = records.clone()
+    if dist.is_initialized():
+        flat = torch.empty((world * n_pad, 5), dtype=torch.float64, device=local.device)
+        work = dist.all_gather_into_tensor(flat, local, group=group, async_op=True)
+        return FanGather(work, flat.view(world, n_pad, 5), world, n_pad, n_rays, local)
+    return FanGather(None, local.unsqueeze(0), world, n_pad, n_rays, local)
+
+
 def start_all_gather_fan(end, n_bott, n_surf, status, n_rays, group=None):
     """Pack the local end records and START their all-gather (asynchronous: the collective runs
     on RCCL's stream behind the work already queued, so the next fan can be launched while the

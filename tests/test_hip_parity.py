@@ -529,6 +529,28 @@ def test_edge_shapes_and_inputs(lib):
     assert g["status"][0] == o["status"][0]
 
 
+def test_kernel_packed_end_records(lib):
+    """PGR_PACKED_END: the kernel writes the all-gather's 40-byte end records itself; they equal
+    pack_end_records() of the separate outputs, padding rows stay zero."""
+    import torch
+    from pygenray_amd.device_fan import DeviceFan
+    from pygenray_amd.distributed import pack_end_records, start_all_gather_records
+    arrs = munk_arrays(80e3)
+    env = lib.EnvHandle(*arrs)
+    th = np.concatenate([np.linspace(-20, 20, 150), [89.9995]])
+    y0 = y0_for(oracle, arrs, 1000.0, 0.0, th)
+    plain = DeviceFan(env, y0, 0.0, 80e3, 2, save=False)
+    plain.run()
+    packed = DeviceFan(env, y0, 0.0, 80e3, 2, save=False, packed_end=True, n_pad=160)
+    packed.run(); torch.cuda.synchronize()
+    want = pack_end_records(plain.end, plain.n_bott, plain.n_surf, plain.status, 160)
+    assert packed.records.shape == (160, 5)
+    assert torch.equal(packed.records.view(torch.int64), want.view(torch.int64))   # bitwise, NaNs included
+    assert torch.equal(packed.end.nan_to_num(), plain.end.nan_to_num()) and torch.equal(packed.status, plain.status)
+    e, nb, ns, st = start_all_gather_records(packed.records[:151].contiguous(), 151).finish()  # one rank: a copy
+    assert torch.equal(st, plain.status) and torch.equal(nb, plain.n_bott)
+
+
 def test_sharded_hip_compute_single_rank(lib):
     """distributed.shoot_fan_sharded with the HIP compute callback (world size 1 here; the
     collective itself is covered under gloo in tests/test_host.py)."""

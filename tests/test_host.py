@@ -248,6 +248,16 @@ assert end.shape == (37, 3)
 assert np.array_equal(end.numpy(), ref, equal_nan=True), "gathered fan is not in launch-angle order"
 assert np.array_equal(nb.numpy(), full["n_bott"]) and np.array_equal(ns.numpy(), full["n_surf"])
 assert np.array_equal(st.numpy(), full["status"])
+# the same through records the kernel packs itself (PGR_PACKED_END): start ... finish
+from pygenray_amd.distributed import pack_end_records, start_all_gather_records
+mine0 = shard_indices(37, dist.get_rank(), 2)
+e_l, nb_l, ns_l, st_l = compute(y0[mine0])
+rec = pack_end_records(e_l, nb_l, ns_l, st_l, 19)
+g2 = start_all_gather_records(rec, 37)
+rec.zero_()                          # the next fan may overwrite the records while they travel
+end2, nb2, ns2, st2 = g2.finish()
+assert np.array_equal(end2.numpy(), ref, equal_nan=True) and np.array_equal(st2.numpy(), full["status"])
+assert np.array_equal(nb2.numpy(), full["n_bott"]) and np.array_equal(ns2.numpy(), full["n_surf"])
 mine = shard_indices(37, dist.get_rank(), 2)
 h_local = arrival_time_histogram(end[mine, 0], st[mine], 16, 39.0, 41.0, reduce=True)
 h_full = arrival_time_histogram(end[:, 0], st, 16, 39.0, 41.0)
