@@ -394,10 +394,31 @@ def g8_timing():
           f"{out['n_steps'].sum()} ray-steps -> {out['n_steps'].sum() / dt:.0f} ray-steps/s")
 
 
+def g9_irregular_grids():
+    """Grids the table look-up has to SEARCH: a randomly spaced range grid (cells of 50 m ... 3 km,
+    so that loose-tolerance steps span several cells), a randomly spaced bathymetry with slopes and
+    a stretched depth grid; range-dependent sound speed.  rtol 1e-9 and 1e-5."""
+    rng = np.random.default_rng(9)
+    z = 5500.0 * np.linspace(0, 1, 900) ** 1.25
+    r = np.sort(np.concatenate([[0.0, 70e3], rng.uniform(0, 70e3, 120)]))
+    c2d = np.array([munk_ssp(z, sofar_depth=1200 + 3e-3 * ri) for ri in r])
+    br = np.sort(np.concatenate([[0.0, 70e3], rng.uniform(0, 70e3, 17)]))
+    bathy = 4600.0 + 250.0 * np.sin(br / 11e3)
+    env = DuckEnv(c2d, r, z, bathy, br)
+    arrs = env_arrays(env)
+    theta = np.array([-17.0, -11.0, -6.0, -1.5, 3.0, 7.5, 12.0, 16.0])
+    out = {}
+    for tag, rtol in (("t9_", 1e-9), ("t5_", 1e-5)):
+        o = shoot_array_level(arrs, 600.0, 1e3, 69e3, theta, 61, rtol=rtol)
+        out.update({tag + k: v for k, v in o.items()})
+    save("g9_irregular_grids.npz", theta_ode=theta, **pack_env(arrs), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     table = dict(g1=g1_fixture_case, g2=g2_munk_100km, g3=g3_munk_1000km, g4=g4_range_dependent,
-                 g5=g5_analytic_envs, g6=g6_eigenrays, g7=g7_unit_vectors, g8=g8_timing)
+                 g5=g5_analytic_envs, g6=g6_eigenrays, g7=g7_unit_vectors, g8=g8_timing,
+                 g9=g9_irregular_grids)
     for w in which:
         print(w)
         table[w]()

@@ -89,6 +89,17 @@ def test_golden_munk_100km(lib):
     assert np.array_equal(out["n_steps"][quiet], g["n_steps"][quiet])
 
 
+def test_golden_irregular_range_bathymetry_and_depth_grids(lib):
+    """g9 (reference output): randomly spaced rin / bathymetry ranges, stretched zin, range-dependent c,
+    at rtol 1e-9 and at 1e-5 (steps wider than several range cells)."""
+    g = load("g9_irregular_grids.npz")
+    arrs = env_from(g)
+    golden_check(lib, g, arrs, 1e3, 69e3, 61, prefix="t9_", rtol=1e-9, label="g9 rtol 1e-9")
+    out = golden_check(lib, g, arrs, 1e3, 69e3, 61, prefix="t5_", rtol=1e-5, label="g9 rtol 1e-5")
+    assert np.array_equal(out["n_steps"], g["t5_n_steps"])
+    assert np.array_equal(out["n_bott"], g["t5_n_bott"]) and np.array_equal(out["n_surf"], g["t5_n_surf"])
+
+
 def test_golden_munk_1000km(lib):
     g = load("g3_munk_1000km.npz")
     out = golden_check(lib, g, tiled_env(g), 0.0, 1000e3, 101, label="g3")

@@ -172,6 +172,18 @@ def test_range_dependent_forward_and_mirrored():
                          abs_floor=floor)
 
 
+def test_irregular_range_bathymetry_and_depth_grids():
+    """g9: randomly spaced rin (50 m ... 3 km cells) and bathymetry ranges, stretched zin,
+    range-dependent c: every table look-up is a search; at rtol 1e-5 one step spans several cells."""
+    g = load("g9_irregular_grids.npz")
+    arrs = env_from(g)
+    # rtol 1e-9 on a grid with kinks every few metres: accept/reject decisions sit on the last bit, the
+    # step counts differ by one on some rays and the 1-ulp self-noise bound carries the comparison
+    check_against_golden(g, arrs, 1e3, 69e3, 61, prefix="t9_", rtol=1e-9, label="g9 rtol 1e-9", step_slack=0.04)
+    _, worst = check_against_golden(g, arrs, 1e3, 69e3, 61, prefix="t5_", rtol=1e-5, label="g9 rtol 1e-5")
+    assert max(worst.values()) < 1e-9, worst
+
+
 def test_range_dependent_config2_subset():
     g = load("g4_config2_subset.npz")
     from helpers import munk
