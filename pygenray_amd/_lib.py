@@ -6,6 +6,7 @@ is never imported from here).
 """
 import ctypes
 import os
+import sys
 import subprocess
 
 import numpy as np
@@ -52,24 +53,98 @@ class PgrError(RuntimeError):
     pass
 
 
+def _llvm_bin():
+    return os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(HIPCC))), "lib", "llvm", "bin")
+
+
+def _relayout(td, verbose):
+    """Second pass of the build (pygenray_amd/_isa_layout.py): re-encode 4-byte VALU instructions as
+    8-byte ones where that keeps 8-byte instructions from straddling a 32-byte fetch window, then
+    assemble, link and bundle the device code again and put it into the host object.  Works on the
+    intermediates hipcc -save-temps left in `td`; returns the path of the finished library."""
+    import re
+    from . import _isa_layout
+    B = _llvm_bin()
+    dev_s = os.path.join(td, "pgr_hip-hip-amdgcn-amd-amdhsa-gfx950.s")
+    dev_o = os.path.join(td, "pgr_hip-hip-amdgcn-amd-amdhsa-gfx950.o")
+    host_s = os.path.join(td, "pgr_hip-host-x86_64-unknown-linux-gnu.s")
+    layout = _isa_layout.object_layout(os.path.join(B, "llvm-objdump"), dev_o)
+    with open(dev_s) as f:
+        text, report = _isa_layout.relayout(f.read(), layout)
+    dev2_s, dev2_o = os.path.join(td, "dev2.s"), os.path.join(td, "dev2.o")
+    dev2_out, fb = os.path.join(td, "dev2.out"), os.path.join(td, "dev2.hipfb")
+    with open(dev2_s, "w") as f:
+        f.write(text)
+    run = lambda c: subprocess.check_call(c, cwd=td)
+    run([os.path.join(B, "clang"), "-cc1as", "-triple", "amdgcn-amd-amdhsa", "-filetype", "obj",
+         "-main-file-name", "pgr_hip.hip", "-target-cpu", "gfx950", "-mrelocation-model", "pic",
+         "-o", dev2_o, dev2_s])
+    # the re-encoded object must hold the same instructions in the same order
+    after = _isa_layout.object_layout(os.path.join(B, "llvm-objdump"), dev2_o)
+    _isa_layout.check_same_program(layout, after)
+    run([os.path.join(B, "lld"), "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared",
+         "-plugin-opt=-amdgpu-internalize-symbols", "-plugin-opt=mcpu=gfx950", "-plugin-opt=O3",
+         "--whole-archive", "-o", dev2_out, dev2_o, "--no-whole-archive"])
+    run([os.path.join(B, "clang-offload-bundler"), "-type=o", "-bundle-align=4096",
+         "-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950",
+         "-input=/dev/null", f"-input={dev2_out}", f"-output={fb}"])
+    # the host assembly carries the fat binary as one string: point it at the new bundle instead
+    with open(host_s, "rb") as f:
+        h = f.read()
+    i = h.index(b'\t.asciz\t"__CLANG_OFFLOAD_BUNDLE__')
+    j = h.index(b"\n", i)
+    k = h.index(b"\n", j + 1)
+    m = re.match(rb"\t\.size\t(\S+), (\d+)", h[j + 1:k])
+    if not m:
+        raise RuntimeError("unexpected layout of the fat binary in the host assembly")
+    h = (h[:i] + b'\t.incbin\t"' + fb.encode() + b'"\n\t.size\t' + m.group(1) + b", " +
+         str(os.path.getsize(fb)).encode() + h[k:])
+    host2_s, host2_o = os.path.join(td, "host2.s"), os.path.join(td, "host2.o")
+    with open(host2_s, "wb") as f:
+        f.write(h)
+    run([os.path.join(B, "clang"), "-c", host2_s, "-o", host2_o])
+    out = os.path.join(td, "relaid.so")
+    run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, host2_o])
+    if verbose:
+        b = sum(v[0] for v in report.values()); a = sum(v[1] for v in report.values())
+        print(f"instruction layout: {b} -> {a} 8-byte instructions straddle a 32-byte fetch window "
+              f"({sum(v[2] for v in report.values())} re-encoded as e64)")
+    return out
+
+
 def build(force=False, verbose=False):
-    """Compile csrc/pgr_hip.hip for gfx950 (cross-compiles without a GPU)."""
+    """Compile csrc/pgr_hip.hip for gfx950 (cross-compiles without a GPU): hipcc, then the
+    instruction-layout pass over its assembly (_relayout; PGR_NO_RELAYOUT=1 or any failure of that
+    pass leaves the plain hipcc build in place)."""
+    import shutil
+    import tempfile
     src = os.path.join(CSRC, "pgr_hip.hip")
     hdr = os.path.join(_HERE, "..", "include", "pgr.h")
     if not force and os.path.exists(LIB_PATH):
-        newest = max(os.path.getmtime(src), os.path.getmtime(hdr))
+        newest = max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(os.path.join(_HERE, "_isa_layout.py")))
         if os.path.getmtime(LIB_PATH) >= newest:
             return LIB_PATH
     tmp = f"{LIB_PATH}.{os.getpid()}.tmp"   # never leave a half-written library behind
-    cmd = [HIPCC] + HIPCC_FLAGS + ["-o", tmp, src]
-    if verbose:
-        print(" ".join(cmd))
+    td = tempfile.mkdtemp(prefix="pgr_build_")
     try:
-        subprocess.check_call(cmd)
+        plain = os.path.join(td, "plain.so")
+        cmd = [HIPCC] + HIPCC_FLAGS + ["-save-temps", "-o", plain, src]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd, cwd=td)
+        result = plain
+        if not os.environ.get("PGR_NO_RELAYOUT"):
+            try:
+                result = _relayout(td, verbose)
+            except Exception as e:  # the plain build is complete and correct: keep it, say why
+                print(f"pygenray_amd: instruction-layout pass skipped ({type(e).__name__}: {e})", file=sys.stderr)
+        shutil.copyfile(result, tmp)
+        os.chmod(tmp, 0o755)
         os.replace(tmp, LIB_PATH)
     finally:
         if os.path.exists(tmp):
             os.remove(tmp)
+        shutil.rmtree(td, ignore_errors=True)
     return LIB_PATH
 
 

@@ -254,6 +254,14 @@ __device__ __forceinline__ double grid_at(double g0, double dg, int j)
     return g0 + m;
 }
 
+// min(max(j, 0), hi) for hi >= 0 in one instruction
+__device__ __forceinline__ int clamp_index(int j, int hi)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(j), "s"(hi));
+    return r;
+}
+
 // ------------------------------------------------------------------------------------
 // grid cell lookup: np.searchsorted(grid, q) - 1 clamped to [0, n-2]
 // (REF/integration_processes.py:152-157).  side='left': grid[j] < q <= grid[j+1].
@@ -461,8 +469,12 @@ struct Ctx {
             }
         } else if (ZS) {
             const double t = (ZM == 4) ? z : z * h_inv_dz;  // exact
-            // v_cvt_i32_f64 saturates and maps NaN to 0: no clamp needed before the conversion
-            j = min(max((int)ceil(t) - 1, 0), h_nz - 2);
+            // searchsorted(side='left') puts a z that IS a node into the cell above it (weight 1);
+            // the cell below it (weight 0) blends to the same bits: the node's two products, each
+            // rounded once, plus exact zeros.  So the truncating conversion serves (trunc = floor
+            // for t >= 0, clamped to 0 below; v_cvt_i32_f64 saturates and maps NaN to 0), and the
+            // clamp is one v_med3_i32: 4 instructions per look-up instead of 7.
+            j = clamp_index((int)t, h_nz - 2);
             // (z - zin[j]) / dz, an exact scaling (by 1 when ZM == 4: the same bits without the multiplies)
             f.wy = (ZM == 4) ? (z - (double)j) : (z - (double)j * h_dz) * h_inv_dz;
         } else {
@@ -536,7 +548,14 @@ struct Ctx {
         double cp;
         blend(ft, wx, c, cp);
         double arg = 1.0 - (c * c) * (pz * pz);
+#if PGR_FAST
+        // `if arg <= 0: arg = 1e-30` as one v_max_f64: 1 - x is 0, negative or >= 2^-53, never in
+        // (0, 1e-30).  (A NaN arg -- c or pz NaN -- becomes 1e-30 here; d1 and d2 are NaN through
+        // their own factors all the same, and the error norm with them.)
+        arg = fmax(arg, 1e-30);
+#else
         if (arg <= 0.0) arg = 1e-30;
+#endif
 #if PGR_FAST
         double fact = frsqrt(arg);
         double rc = frcp_seed(c);  // seeds both quotients below (1/c and, squared, 1/c^2)
@@ -708,18 +727,36 @@ struct Dense {
 // (t, y, f, h), by the service phase of a lane that parked on this step: IEEE arithmetic in a
 // fixed order, so the replay reproduces every bit and nothing has to be kept while parked.
 #define PGR_SB() __builtin_amdgcn_sched_barrier(0)
+// -DPGR_TIMING (experiments only): s_memtime stamps along one step attempt; the time between stamp
+// k-1 and stamp k accumulates in tacc[k] and comes back in n_rej[] of lanes 0..23 (scripts/phase_times.py)
+#ifdef PGR_TIMING
+#define PGR_STAMP(k)                                                                                 \
+    do {                                                                                             \
+        unsigned long long _t;                                                                       \
+        PGR_SB();                                                                                    \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) : : "memory"); \
+        tacc[k] += (unsigned)_t - tprev;                                                             \
+        tprev = (unsigned)_t;                                                                        \
+        PGR_SB();                                                                                    \
+    } while (0)
+#else
+#define PGR_STAMP(k) do { } while (0)
+#endif
 #define PGR_RK_STAGES(T_, H_)                                                                        \
     double k20, k21, k22, k30, k31, k32, k40, k41, k42, k50, k51, k52, k60, k61, k62, k70, k71, k72, \
         cs;                                                                                          \
     double wr[5];                                                                                    \
     int ir[5];                                                                                       \
+    PGR_STAMP(1);                                                                                    \
     C.step_weights(T_, H_, wr, ir);                                                                  \
+    PGR_STAMP(2);                                                                                    \
     /* Every sum over stages -- sum_j A[s][j] K_j, K.T @ B, K.T @ E -- is accumulated term by term   \
        as each K_j arrives: the same additions in the same order as SciPy's dot products.  The       \
        terms that the NEXT stage does not need sit between the issue of that stage's table read      \
        (fetch) and its first use (rhs_f), fenced by scheduling barriers: ~90 cycles of read latency  \
        per stage that a single in-order wave would otherwise idle through. */                       \
     const double zs2 = y1 + (f1 * vA21) * (H_), ps2 = y2 + (f2 * vA21) * (H_);                         \
+    PGR_STAMP(3);                                                                                    \
     const auto ft2 = C.fetch(ir[0], zs2);                                                            \
     PGR_SB();                                                                                        \
     double a31 = f1 * vA31, a32 = f2 * vA31, a41 = f1 * vA41, a42 = f2 * vA41, a51 = f1 * vA51,           \
@@ -727,8 +764,10 @@ struct Dense {
     double bs0 = f0 * vB1, bs1 = f1 * vB1, bs2 = f2 * vB1, es0 = f0 * vE1, es1 = f1 * vE1, es2 = f2 * vE1; \
     PGR_SB();                                                                                        \
     C.rhs_f(ft2, wr[0], ps2, k20, k21, k22, cs);                                                     \
+    PGR_STAMP(4);                                                                                    \
     a31 = a31 + k21 * vA32; a32 = a32 + k22 * vA32;                                                    \
     const double zs3 = y1 + a31 * (H_), ps3 = y2 + a32 * (H_);                                       \
+    PGR_STAMP(5);                                                                                    \
     const auto ft3 = C.fetch(ir[1], zs3);                                                            \
     PGR_SB();                                                                                        \
     a41 = a41 + k21 * vA42; a42 = a42 + k22 * vA42;                                                    \
@@ -736,8 +775,10 @@ struct Dense {
     a61 = a61 + k21 * vA62; a62 = a62 + k22 * vA62;                                                    \
     PGR_SB();                                                                                        \
     C.rhs_f(ft3, wr[1], ps3, k30, k31, k32, cs);                                                     \
+    PGR_STAMP(6);                                                                                    \
     a41 = a41 + k31 * vA43; a42 = a42 + k32 * vA43;                                                    \
     const double zs4 = y1 + a41 * (H_), ps4 = y2 + a42 * (H_);                                       \
+    PGR_STAMP(7);                                                                                    \
     const auto ft4 = C.fetch(ir[2], zs4);                                                            \
     PGR_SB();                                                                                        \
     a51 = a51 + k31 * vA53; a52 = a52 + k32 * vA53;                                                    \
@@ -746,8 +787,10 @@ struct Dense {
     es0 = es0 + k30 * vE3; es1 = es1 + k31 * vE3; es2 = es2 + k32 * vE3;                                \
     PGR_SB();                                                                                        \
     C.rhs_f(ft4, wr[2], ps4, k40, k41, k42, cs);                                                     \
+    PGR_STAMP(8);                                                                                    \
     a51 = a51 + k41 * vA54; a52 = a52 + k42 * vA54;                                                    \
     const double zs5 = y1 + a51 * (H_), ps5 = y2 + a52 * (H_);                                       \
+    PGR_STAMP(9);                                                                                    \
     const auto ft5 = C.fetch(ir[3], zs5);                                                            \
     PGR_SB();                                                                                        \
     a61 = a61 + k41 * vA64; a62 = a62 + k42 * vA64;                                                    \
@@ -755,18 +798,22 @@ struct Dense {
     es0 = es0 + k40 * vE4; es1 = es1 + k41 * vE4; es2 = es2 + k42 * vE4;                                \
     PGR_SB();                                                                                        \
     C.rhs_f(ft5, wr[3], ps5, k50, k51, k52, cs);                                                     \
+    PGR_STAMP(10);                                                                                   \
     a61 = a61 + k51 * vA65; a62 = a62 + k52 * vA65;                                                    \
     const double zs6 = y1 + a61 * (H_), ps6 = y2 + a62 * (H_);                                       \
+    PGR_STAMP(11);                                                                                   \
     const auto ft6 = C.fetch(ir[4], zs6);                                                            \
     PGR_SB();                                                                                        \
     bs0 = bs0 + k50 * vB5; bs1 = bs1 + k51 * vB5; bs2 = bs2 + k52 * vB5;                                \
     es0 = es0 + k50 * vE5; es1 = es1 + k51 * vE5; es2 = es2 + k52 * vE5;                                \
     PGR_SB();                                                                                        \
     C.rhs_f(ft6, wr[4], ps6, k60, k61, k62, cs);                                                     \
+    PGR_STAMP(12);                                                                                   \
     /* y_new = y + h * (K[:-1].T @ B)   (B[1] = 0) */                                                \
     bs1 = bs1 + k61 * vB6; bs2 = bs2 + k62 * vB6;                                                      \
     const double n1 = y1 + (H_) * bs1, n2 = y2 + (H_) * bs2;                                         \
     /* f_new at t + h: the stage-6 abscissa */                                                       \
+    PGR_STAMP(13);                                                                                   \
     const auto ft7 = C.fetch(ir[4], n1);                                                             \
     PGR_SB();                                                                                        \
     bs0 = bs0 + k60 * vB6;                                                                            \
@@ -775,6 +822,7 @@ struct Dense {
     PGR_SB();                                                                                        \
     double c_new;                                                                                    \
     C.rhs_f(ft7, wr[4], n2, k70, k71, k72, c_new);                                                   \
+    PGR_STAMP(14);                                                                                   \
     /* K.T @ E complete (E[1] = 0), SCIPY/rk.py:106-110 */                                           \
     es0 = es0 + k70 * vE7; es1 = es1 + k71 * vE7; es2 = es2 + k72 * vE7
 
@@ -906,6 +954,11 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     unsigned pk_active = 0;
     int waited = 0;
     int trips = 0, services = 0, fallbacks = 0;  // diagnostics (PGR_DEBUG_TRIPS)
+#ifdef PGR_TIMING
+    unsigned tacc[24];
+    for (int k = 0; k < 24; k++) tacc[k] = 0;
+    unsigned tprev = (unsigned)clock64();
+#endif
     const int64_t out_off = ray * a.stride_ray;
 #define Tp (a.T + out_off)
 #define Zp (a.Z + out_off)
@@ -975,6 +1028,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
         // only taken branch is its own back-edge)
         do {
         trips++;
+        PGR_STAMP(0);
         if (status == RUNNING && !parked && !need_init) {
             // ---- one attempt of RK45._step_impl, SCIPY/rk.py:111-176 ----
             double min_step = min_step_of(t);
@@ -995,6 +1049,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
             double er1 = fdiv(es1 * h, sc1);
             double er2 = fdiv(es2 * h, sc2);
             double error_norm = rms3(er0, er1, er2);
+            PGR_STAMP(15);
 
             // ---- accept / reject and the next step size, SCIPY/rk.py:148-165, without branches: a
             // taken skip-branch costs a lone in-order wave ~80 cycles (scripts/probes/branch_probe2),
@@ -1014,11 +1069,13 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
             n_rej += reject ? 1 : 0;
             const bool over = (int64_t)((unsigned)n_rej + (unsigned)n_steps) > attempt_limit;
             status = too_small ? PGR_RAY_STEP_TOO_SMALL : ((reject & over) ? PGR_RAY_MAX_STEPS : status);
+            PGR_STAMP(16);
 
             if (accepted) {
                 n_steps++;
                 // events at the new point, SCIPY/ivp.py:671-675 (c at (t_new, y_new) is the FSAL lookup)
                 unsigned g_new = C.events(t_new, n1, n2, c_new);
+                PGR_STAMP(17);
                 // find_active_events, SCIPY/ivp.py:133-156: values are +-1, so "up" = -1 -> +1,
                 // "down" = +1 -> -1; surface/bottom need "up", vertical/bbox take either
                 unsigned up = (~g) & g_new, down = g & (~g_new);
@@ -1095,8 +1152,10 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                     if ((t - t_bound) >= 0) status = PGR_RAY_OK;  // SCIPY/base.py:197
                     else if (n_steps > a.max_steps) status = PGR_RAY_MAX_STEPS;
                 }
+                PGR_STAMP(18);
             }
         }
+        PGR_STAMP(19);
         run = (status == RUNNING);
         pend = run && (parked || need_init);
         pm = __ballot(pend);
@@ -1351,6 +1410,13 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
         a.n_surf[ray] = ns;
         a.status[ray] = status;
         if (a.n_steps) a.n_steps[ray] = n_steps;
+#ifdef PGR_TIMING
+        if ((threadIdx.x & 63) < 24) {
+            unsigned v = 0;
+            for (int k = 0; k < 24; k++) v = ((threadIdx.x & 63) == k) ? tacc[k] : v;
+            n_rej = (int)v;
+        }
+#endif
         if (a.n_rej) a.n_rej[ray] = (a.flags & PGR_DEBUG_TRIPS) ? (((threadIdx.x & 63) == 0) ? trips : (((threadIdx.x & 63) == 1) ? services : fallbacks)) : n_rej;
     }
 #undef Tp
