@@ -358,6 +358,11 @@ struct Ctx {
     const double* const h_zin;
     const double* const h_rin;
     const int h_nz, h_nr, h_r_uniform;
+    // fp64 literals of the step attempt.  An fp64 literal cannot be an inline operand (two s_mov_b32
+    // per use, and every instruction of a lone wave costs an issue slot); the fan kernel pins these
+    // in VGPRs (PGR_PIN below) where it has registers to spare, everywhere else they fold back
+    // into literals.
+    mutable double k_c2 = C2, k_c3 = C3, k_c4 = C4, k_c5 = C5, k_tiny = 1e-30, k_vert = 0.9999999998;
     __device__ __forceinline__ Ctx(const EnvDev& e_, const double2* l, const double* lz = nullptr,
                                    const unsigned short* lzb = nullptr, const double* lbx = nullptr)
         : e(e_), lds(l), bx(lbx ? lbx : e_.depth_ranges), bd(lbx ? lbx + e_.nb : e_.depths), lds_z(lz),
@@ -552,7 +557,7 @@ struct Ctx {
         // `if arg <= 0: arg = 1e-30` as one v_max_f64: 1 - x is 0, negative or >= 2^-53, never in
         // (0, 1e-30).  (A NaN arg -- c or pz NaN -- becomes 1e-30 here; d1 and d2 are NaN through
         // their own factors all the same, and the error norm with them.)
-        arg = fmax(arg, 1e-30);
+        arg = fmax(arg, k_tiny);
 #else
         if (arg <= 0.0) arg = 1e-30;
 #endif
@@ -580,7 +585,7 @@ struct Ctx {
     // search left elsewhere) goes stage by stage through weight_r.
     __device__ __forceinline__ void step_weights(double t, double h, double (&w)[5], int (&ic)[5]) const
     {
-        const double xs[5] = {t + C2 * h, t + C3 * h, t + C4 * h, t + C5 * h, t + 1.0 * h};
+        const double xs[5] = {t + k_c2 * h, t + k_c3 * h, t + k_c4 * h, t + k_c5 * h, t + 1.0 * h};
         if (__builtin_expect((t >= r_lo) & (xs[4] <= r_hi), 1)) {
             const double den = r_hi - r_lo;
 #pragma unroll
@@ -631,7 +636,7 @@ struct Ctx {
         // vertical: only |pc| within 2e-10 of 1 can reach 90 - 1e-3 degrees.  Both tests sit in ONE
         // rarely entered block: every skipped block is a taken branch on the step's critical path.
         const bool near_bottom = (pc > 0) & (pc <= 1.0) & !((z < h_b_zmin) & (x >= h_b_xlo) & (x <= h_b_xhi));
-        const bool near_vertical = (fabs(pc) > 0.9999999998) & (fabs(pc) <= 1.0);
+        const bool near_vertical = (fabs(pc) > k_vert) & (fabs(pc) <= 1.0);
         if (near_bottom | near_vertical) {
             if (near_bottom) {
                 if (z > bathy(x)) g |= 2u;
@@ -646,12 +651,13 @@ struct Ctx {
     }
 };
 
-__device__ __forceinline__ double rms3(double a, double b, double c)
+__device__ __forceinline__ double rms3(double a, double b, double c, double sqrt3 = 1.7320508075688772,
+                                       double inv_sqrt3 = 0.57735026918962584)
 {
     // np.linalg.norm(x) / x.size ** 0.5, SCIPY/common.py:63-65
 #if PGR_FAST
     // x / 3**0.5 with the (correctly rounded) reciprocal of the constant as Markstein seed
-    return fdiv_y(fsqrt(a * a + b * b + c * c), 1.7320508075688772, 0.57735026918962584);
+    return fdiv_y(fsqrt(a * a + b * b + c * c), sqrt3, inv_sqrt3);
 #else
     return sqrt(a * a + b * b + c * c) / 1.7320508075688772;
 #endif
@@ -921,7 +927,8 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     }
     const int64_t ray = gwave * 64 + (threadIdx.x & 63);
     const bool valid = (gwave >= 0) && (ray < a.N);
-    const double SAFETY = 0.9, MIN_FACTOR = 0.2, MAX_FACTOR = 10;
+    double SAFETY = 0.9, MIN_FACTOR = 0.2, MAX_FACTOR = 10, ERR_LO = 5.0e-6, ERR_HI = 1800.0,
+           SQRT3 = 1.7320508075688772, INV_SQRT3 = 0.57735026918962584;
     const double rtol = a.rtol, atol = a.atol, t_bound = a.x1;
     const int S = a.S;
     constexpr bool save = (SAVE != 0);  // trajectories wanted (a.T != nullptr)
@@ -1017,6 +1024,18 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     PGR_VCONST_IF(SAVE != 0, P72);
     PGR_VCONST_IF(SAVE != 0, P73);
 #undef PGR_VCONST_IF
+    // ... and the remaining fp64 literals of a step attempt (stage abscissae, controller and norm
+    // constants, the RHS clamp): 26 s_mov_b32 per attempt otherwise
+#ifndef PGR_PIN_LITERALS
+#define PGR_PIN_LITERALS (SAVE == 0)
+#endif
+    if (PGR_PIN_LITERALS) {
+#define PGR_PIN(x) asm volatile("" : "+v"(x))
+        PGR_PIN(C.k_c2); PGR_PIN(C.k_c3); PGR_PIN(C.k_c4); PGR_PIN(C.k_c5); PGR_PIN(C.k_tiny); PGR_PIN(C.k_vert);
+        PGR_PIN(SAFETY); PGR_PIN(MIN_FACTOR); PGR_PIN(MAX_FACTOR); PGR_PIN(ERR_LO); PGR_PIN(ERR_HI);
+        PGR_PIN(SQRT3); PGR_PIN(INV_SQRT3);
+#undef PGR_PIN
+    }
     // One trip = one step attempt of every stepping lane, THEN the gate that decides whether the
     // wave services its parked lanes.  (The first trip only runs the gate: every lane starts with
     // need_init.)  The step comes first so that the common path -- nobody parked -- is the loop's
@@ -1048,7 +1067,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
             double er0 = fdiv(es0 * h, sc0);
             double er1 = fdiv(es1 * h, sc1);
             double er2 = fdiv(es2 * h, sc2);
-            double error_norm = rms3(er0, er1, er2);
+            double error_norm = rms3(er0, er1, er2, SQRT3, INV_SQRT3);
             PGR_STAMP(15);
 
             // ---- accept / reject and the next step size, SCIPY/rk.py:148-165, without branches: a
@@ -1061,9 +1080,9 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
             const bool accepted = !too_small && (error_norm < 1);
             const bool reject = !too_small && !accepted;
             const double pw = SAFETY * pow_m02(error_norm);
-            double fac_acc = (error_norm < 5.0e-6) ? MAX_FACTOR : ((pw < MAX_FACTOR) ? pw : MAX_FACTOR);
+            double fac_acc = (error_norm < ERR_LO) ? MAX_FACTOR : ((pw < MAX_FACTOR) ? pw : MAX_FACTOR);
             fac_acc = (rejected && !(fac_acc < 1)) ? 1.0 : fac_acc;
-            const double fac_rej = (error_norm < 1800.0) ? ((pw > MIN_FACTOR) ? pw : MIN_FACTOR) : MIN_FACTOR;
+            const double fac_rej = (error_norm < ERR_HI) ? ((pw > MIN_FACTOR) ? pw : MIN_FACTOR) : MIN_FACTOR;
             h_abs = too_small ? h_abs : h_abs * (accepted ? fac_acc : fac_rej);
             rejected = too_small ? rejected : reject;
             n_rej += reject ? 1 : 0;
