@@ -961,6 +961,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     unsigned pk_active = 0;
     int waited = 0;
     int trips = 0, services = 0, fallbacks = 0;  // diagnostics (PGR_DEBUG_TRIPS)
+    const int max_steps32 = (int)(a.max_steps < 0x7fffffff ? a.max_steps : 0x7fffffff);  // n_steps is an int
 #ifdef PGR_TIMING
     unsigned tacc[24];
     for (int k = 0; k < 24; k++) tacc[k] = 0;
@@ -1168,8 +1169,9 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                     }
                     t = t_new; y0 = n0; y1 = n1; y2 = n2;
                     f0 = k70; f1 = k71; f2 = k72;
-                    if ((t - t_bound) >= 0) status = PGR_RAY_OK;  // SCIPY/base.py:197
-                    else if (n_steps > a.max_steps) status = PGR_RAY_MAX_STEPS;
+                    // (selects, not a skipped block: a taken branch costs more than these four instructions)
+                    status = ((t - t_bound) >= 0) ? PGR_RAY_OK  // SCIPY/base.py:197
+                                                  : ((n_steps > max_steps32) ? PGR_RAY_MAX_STEPS : status);
                 }
                 PGR_STAMP(18);
             }
@@ -1179,6 +1181,10 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
         pend = run && (parked || need_init);
         pm = __ballot(pend);
         } while (pm == 0 && __any(run));
+        // keep ONE exit of the trip loop: without this the compiler threads "left with pm != 0" straight
+        // to the gate and gives the loop two exits, whose unification costs the common path two more
+        // taken branches per trip
+        asm volatile("" : "+s"(pm));
         if (pm) {
             waited++;
             const bool nobody_steps = !__any(run && !pend);
