@@ -254,6 +254,10 @@ __device__ __forceinline__ double grid_at(double g0, double dg, int j)
     return g0 + m;
 }
 
+// the lanes of the wave whose predicate holds, as a mask: HIP's __ballot / __any take an int and
+// compare it with 0 again (v_cndmask + v_cmp per call); the builtin takes the condition mask as it is
+__device__ __forceinline__ unsigned long long ballot64(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+
 // min(max(j, 0), hi) for hi >= 0 in one instruction
 __device__ __forceinline__ int clamp_index(int j, int hi)
 {
@@ -1179,15 +1183,15 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
         PGR_STAMP(19);
         run = (status == RUNNING);
         pend = run && (parked || need_init);
-        pm = __ballot(pend);
-        } while (pm == 0 && __any(run));
+        pm = ballot64(pend);
+        } while (pm == 0 && ballot64(run) != 0);
         // keep ONE exit of the trip loop: without this the compiler threads "left with pm != 0" straight
         // to the gate and gives the loop two exits, whose unification costs the common path two more
         // taken branches per trip
         asm volatile("" : "+s"(pm));
         if (pm) {
             waited++;
-            const bool nobody_steps = !__any(run && !pend);
+            const bool nobody_steps = ballot64(run && !pend) == 0;
             if (__popcll(pm) >= a.park_lanes || waited > a.park_trips || nobody_steps) {
                 waited = 0;
                 services++;
@@ -1398,7 +1402,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                 }
             }
         }
-    } while (__any(status == RUNNING));
+    } while (ballot64(status == RUNNING) != 0);
 
     if (valid) {
         bool ok = (status == PGR_RAY_OK);

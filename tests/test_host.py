@@ -328,3 +328,36 @@ def test_committed_bench_line_and_profiles_are_well_formed():
     assert "pgr_fan_kernel" in stats
     tr = json.load(open(os.path.join(root, "profiles", "r01_traffic.json")))
     assert tr["sample"]["hbm_gb_per_launch"] > 0
+
+
+# ----------------------------------------------------------------------------- build: instruction layout
+def test_instruction_layout_pass_plans_encodings():
+    """pygenray_amd/_isa_layout.py: 4-byte e32 VALU instructions are re-encoded as 8-byte e64 ones
+    exactly where that keeps 8-byte instructions off the 32-byte fetch-window boundaries."""
+    from pygenray_amd import _isa_layout as L
+    # a 4-byte instruction followed by a long run of 8-byte ones: every 4th straddles ...
+    items = [("i", 4, True)] + [("i", 8, False)] * 40
+    promote, before, after = L.plan_function(items)
+    assert before == 10 and after == 0 and promote == {0}
+    # ... and nothing can be done when the 4-byte instruction has no 8-byte encoding
+    items = [("i", 4, False)] + [("i", 8, False)] * 40
+    promote, before, after = L.plan_function(items)
+    assert before == 10 and after == 10 and not promote
+    # an alignment directive restarts the window
+    items = [("i", 4, False), ("a", 6, 0)] + [("i", 8, False)] * 8
+    assert L.plan_function(items)[1:] == (0, 0)
+    # already clean layouts are left alone
+    items = [("i", 8, False), ("i", 4, True), ("i", 4, True)] * 20
+    promote, before, after = L.plan_function(items)
+    assert before == 0 and after == 0 and not promote
+    # which instructions have an e64 twin: plain register / inline-constant operands only
+    assert L.promotable("v_fmac_f64_e32 v[0:1], v[2:3], v[4:5]")
+    assert L.promotable("v_mov_b32_e32 v1, s5")
+    assert L.promotable("v_cndmask_b32_e32 v1, v2, v3, vcc")
+    assert L.promotable("v_cmp_lt_f64_e32 vcc, 0, v[2:3]")
+    assert L.promotable("v_add_u32_e32 v1, -1, v2")
+    assert not L.promotable("v_mov_b32_e32 v1, 0x3ff00000")      # literal: no VOP3 form on gfx9
+    assert not L.promotable("v_add_u32_e32 v1, 1000, v2")
+    assert not L.promotable("v_addc_co_u32_e32 v1, vcc, v2, v3, vcc")
+    assert not L.promotable("v_mul_f64 v[0:1], v[2:3], v[4:5]")  # already 8 bytes
+    assert not L.promotable("s_mov_b32 s0, s1")
