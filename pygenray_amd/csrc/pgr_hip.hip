@@ -1164,7 +1164,9 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     }
                             // two copies so that the linspace one holds no load: a load in the loop
                             // makes every iteration wait (vmcnt) for the stores of the one before
-                            if (SAVE == 1 || G.formula) { PGR_SAMPLE_LOOP(((jnext >= S - 1) ? G.x1 : grid_at(G.x0, G.step, jnext))) }
+                            // (every use of rnext is guarded by jnext < S - 1, so the formula copy needs no
+                            // select for the forced last grid point)
+                            if (SAVE == 1 || G.formula) { PGR_SAMPLE_LOOP(grid_at(G.x0, G.step, jnext)) }
                             else { PGR_SAMPLE_LOOP(G.r[jnext]) }
 #undef PGR_SAMPLE_LOOP
 #undef PGR_SSTORE
