@@ -1009,30 +1009,33 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     PGR_VCONST(E7);
 #undef PGR_VCONST
     // ... and, in the kernels that save trajectories, the 18 coefficients of the stage-major sample form
+#ifndef PGR_PIN_P   // (not where the depth search already fills the register file: those instances spill otherwise)
+#define PGR_PIN_P (SAVE != 0 && ZM != 0 && ZM != 3)
+#endif
 #define PGR_VCONST_IF(c, n) double v##n = n; if (c) asm volatile("" : "+v"(v##n))
-    PGR_VCONST_IF(SAVE != 0, P11);
-    PGR_VCONST_IF(SAVE != 0, P12);
-    PGR_VCONST_IF(SAVE != 0, P13);
-    PGR_VCONST_IF(SAVE != 0, P31);
-    PGR_VCONST_IF(SAVE != 0, P32);
-    PGR_VCONST_IF(SAVE != 0, P33);
-    PGR_VCONST_IF(SAVE != 0, P41);
-    PGR_VCONST_IF(SAVE != 0, P42);
-    PGR_VCONST_IF(SAVE != 0, P43);
-    PGR_VCONST_IF(SAVE != 0, P51);
-    PGR_VCONST_IF(SAVE != 0, P52);
-    PGR_VCONST_IF(SAVE != 0, P53);
-    PGR_VCONST_IF(SAVE != 0, P61);
-    PGR_VCONST_IF(SAVE != 0, P62);
-    PGR_VCONST_IF(SAVE != 0, P63);
-    PGR_VCONST_IF(SAVE != 0, P71);
-    PGR_VCONST_IF(SAVE != 0, P72);
-    PGR_VCONST_IF(SAVE != 0, P73);
+    PGR_VCONST_IF(PGR_PIN_P, P11);
+    PGR_VCONST_IF(PGR_PIN_P, P12);
+    PGR_VCONST_IF(PGR_PIN_P, P13);
+    PGR_VCONST_IF(PGR_PIN_P, P31);
+    PGR_VCONST_IF(PGR_PIN_P, P32);
+    PGR_VCONST_IF(PGR_PIN_P, P33);
+    PGR_VCONST_IF(PGR_PIN_P, P41);
+    PGR_VCONST_IF(PGR_PIN_P, P42);
+    PGR_VCONST_IF(PGR_PIN_P, P43);
+    PGR_VCONST_IF(PGR_PIN_P, P51);
+    PGR_VCONST_IF(PGR_PIN_P, P52);
+    PGR_VCONST_IF(PGR_PIN_P, P53);
+    PGR_VCONST_IF(PGR_PIN_P, P61);
+    PGR_VCONST_IF(PGR_PIN_P, P62);
+    PGR_VCONST_IF(PGR_PIN_P, P63);
+    PGR_VCONST_IF(PGR_PIN_P, P71);
+    PGR_VCONST_IF(PGR_PIN_P, P72);
+    PGR_VCONST_IF(PGR_PIN_P, P73);
 #undef PGR_VCONST_IF
     // ... and the remaining fp64 literals of a step attempt (stage abscissae, controller and norm
     // constants, the RHS clamp): 26 s_mov_b32 per attempt otherwise
 #ifndef PGR_PIN_LITERALS
-#define PGR_PIN_LITERALS (SAVE == 0)
+#define PGR_PIN_LITERALS (SAVE == 0 || ZM == 3)
 #endif
     if (PGR_PIN_LITERALS) {
 #define PGR_PIN(x) asm volatile("" : "+v"(x))

@@ -1,3 +1,4 @@
+import os
 """Kernel time with the reference's DEFAULT environment handling: flat-earth transformed tables
 (non-uniform zin -> the generic depth-cell search) against the untransformed uniform grid."""
 import sys, os
@@ -6,6 +7,8 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 import pygenray_amd as pr
 from pygenray_amd import _lib
+if os.environ.get('PGR_LIB'):   # A/B against another build
+    _lib.LIB_PATH = os.path.abspath(os.environ['PGR_LIB'])
 from pygenray_amd.environment import _unpack_envi
 from pygenray_amd.device_fan import DeviceFan, fan_y0
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
