@@ -122,6 +122,20 @@ int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, double sourc
                          double* p, double* end_state, int32_t* n_bott, int32_t* n_surf,
                          int32_t* status, int32_t* n_steps, int32_t* n_rej, void* stream);
 
+/* Arrival-time histogram of a fan's surviving rays on the device (BASELINE configs[4]; the
+ * reduction behind pygenray's time-front scatter RayFan.plot_time_front, REF/ray_objects.py:157-222;
+ * no reference counterpart for the binning itself, so it is NumPy's):
+ * counts[nbins] (DEVICE, int64, overwritten) = np.histogram(T, bins=nbins, range=(t_min, t_max))[0]
+ * over the rays k < N with status[k * status_stride] == 0 (status may be NULL = all rays) and T =
+ * t_end[k * t_stride] not NaN; t_end / status are DEVICE pointers on `device`: e.g. end_state with
+ * t_stride 3, or the packed end records (PGR_PACKED_END) with t_stride 5 and (int32*)(rec + 4) with
+ * status_stride 10.  Enqueued on `stream`, returns without synchronising; every rank of a sharded
+ * fan then all-reduces its counts.  nbins <= 16384. */
+int pgr_arrival_histogram_device(int device, const double* t_end, int64_t t_stride,
+                                 const int32_t* status, int64_t status_stride, int64_t N,
+                                 double t_min, double t_max, int32_t nbins, int64_t* counts,
+                                 void* stream);
+
 /* Depth-cell search for a non-uniform zin (never changes results): 0 (default) = from LDS: the cell
  * of z is j0 or j0 + 1 with j0 = floor(g(z) - 0.5) from a quadratic index estimate g when zin is
  * smooth enough (the flat-earth grid is), else j0 = bucket[floor((z - z0)/w)] from a bin table;

@@ -329,6 +329,18 @@ def device_count():
     return load().pgr_device_count()
 
 
+def arrival_histogram_device(device, t_ptr, t_stride, status_ptr, status_stride, n, t_min, t_max, nbins,
+                             counts_ptr, stream=0):
+    """pgr_arrival_histogram_device on raw device pointers (ints); see include/pgr.h."""
+    L = load()
+    L.pgr_arrival_histogram_device.restype = ctypes.c_int
+    L.pgr_arrival_histogram_device.argtypes = [ctypes.c_int, _vp, _i64, _vp, _i64, _i64, ctypes.c_double,
+                                               ctypes.c_double, ctypes.c_int32, _vp, _vp]
+    check(L.pgr_arrival_histogram_device(int(device), _vp(t_ptr), int(t_stride), _vp(status_ptr or None),
+                                         int(status_stride), int(n), float(t_min), float(t_max), int(nbins),
+                                         _vp(counts_ptr), _vp(stream or None)))
+
+
 def set_depth_search(mode):
     """0: automatic (index polynomial or bucket table in LDS for a non-uniform zin), 1: binary search,
     2: bucket table only."""

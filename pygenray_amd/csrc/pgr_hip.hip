@@ -2232,6 +2232,63 @@ extern "C" int pgr_shoot_fan(pgr_env* env, const double* y0, int64_t N, double s
     return 0;
 }
 
+// ------------------------------------------------------------------------------------
+// arrival-time histogram of a fan's surviving rays (BASELINE configs[4]; the reduction behind
+// pygenray's time-front scatter, REF/ray_objects.py:157-222).  Bin rule = np.histogram(t,
+// bins=nbins, range=(t_min, t_max)) to the bit: uniform-bin index from ((t - first) / width) * nbins,
+// corrected against the np.linspace edges, last bin closed on the right; NaN and rays with
+// status != 0 are skipped.  Per-workgroup counts in LDS, one global atomic per non-empty bin.
+// ------------------------------------------------------------------------------------
+__global__ void pgr_hist_kernel(const double* __restrict__ t, int64_t t_stride, const int32_t* __restrict__ status,
+                                int64_t s_stride, int64_t N, double first, double last, int nbins,
+                                unsigned long long* __restrict__ counts)
+{
+    extern __shared__ unsigned int hist_lds[];
+    for (int i = threadIdx.x; i < nbins; i += blockDim.x) hist_lds[i] = 0;
+    __syncthreads();
+    const double denom = last - first;
+    const double step = denom / nbins;  // np.linspace: step = delta / div; edges = arange * step + start
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < N; k += (int64_t)gridDim.x * blockDim.x) {
+        if (status && status[k * s_stride] != 0) continue;
+        const double v = t[k * t_stride];
+        if (!((v >= first) & (v <= last))) continue;  // also drops NaN
+        int idx = (int)(((v - first) / denom) * nbins);
+        if (idx == nbins) idx--;
+        const double e_lo = (idx == nbins) ? last : grid_at(first, step, idx);
+        if (v < e_lo) idx--;
+        const double e_hi = (idx + 1 >= nbins) ? last : grid_at(first, step, idx + 1);
+        if ((v >= e_hi) & (idx != nbins - 1)) idx++;
+        atomicAdd(&hist_lds[idx], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nbins; i += blockDim.x)
+        if (hist_lds[i]) atomicAdd(&counts[i], (unsigned long long)hist_lds[i]);
+}
+
+extern "C" int pgr_arrival_histogram_device(int device, const double* t_end, int64_t t_stride,
+                                            const int32_t* status, int64_t status_stride, int64_t N,
+                                            double t_min, double t_max, int32_t nbins, int64_t* counts,
+                                            void* stream)
+{
+    if ((!t_end && N > 0) || !counts || N < 0 || t_stride < 1 || (status && status_stride < 1))
+        return fail("pgr_arrival_histogram_device: bad argument");
+    if (nbins < 1 || nbins > 16384) return fail("pgr_arrival_histogram_device: nbins must be 1..16384");
+    if (!(t_max > t_min) || !isfinite(t_min) || !isfinite(t_max))
+        return fail("pgr_arrival_histogram_device: need finite t_min < t_max");
+    HIPCHK(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipMemsetAsync(counts, 0, (size_t)nbins * 8, st));
+    if (N == 0) return 0;
+    const int threads = 256;
+    int64_t blocks = (N + threads * 8 - 1) / (threads * 8);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(pgr_hist_kernel, dim3((unsigned)blocks), dim3(threads), (size_t)nbins * 4, st, t_end, t_stride,
+                       status, status_stride, N, t_min, t_max, (int)nbins, (unsigned long long*)counts);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 extern "C" int pgr_debug_math(const double* a, const double* b, int64_t M, double* out6)
 {
     if (!a || !b || !out6 || M <= 0) return fail("pgr_debug_math: bad argument");

@@ -114,12 +114,27 @@ def hip_compute(env_handle, source_range, receiver_range, rtol=1e-9, atol=1e-6,
 
 
 def arrival_time_histogram(t_end, status, bins, t_min, t_max, group=None, reduce=False):
-    """Histogram of arrival times of the surviving rays (the device-side reduction behind
-    pygenray's time-front scatter ``RayFan.plot_time_front``, REF/ray_objects.py:157-222).
-    With ``reduce=True`` `t_end` is this rank's shard and the bins are summed over ranks
-    (all-reduce); with the all-gathered fan every rank can histogram locally."""
-    t = t_end[(status == 0) & torch.isfinite(t_end)]
-    h = torch.histc(t, bins=int(bins), min=float(t_min), max=float(t_max))
+    """Histogram (int64 counts) of the arrival times of the surviving rays -- the reduction behind
+    pygenray's time-front scatter ``RayFan.plot_time_front``, REF/ray_objects.py:157-222; bins as
+    ``np.histogram(t, bins, range=(t_min, t_max))``.  Device tensors go through the HIP kernel behind
+    ``pgr_arrival_histogram_device`` (strided views such as ``end[:, 0]`` are read in place); host
+    tensors (the gloo rehearsal of the multi-GPU logic) through NumPy itself.  With ``reduce=True``
+    `t_end` is this rank's shard and the bins are summed over ranks (all-reduce); with the
+    all-gathered fan every rank can histogram locally."""
+    bins = int(bins)
+    if t_end.is_cuda:
+        from . import _lib
+        if t_end.dtype != torch.float64 or status.dtype != torch.int32 or t_end.dim() != 1 or status.dim() != 1:
+            raise TypeError("arrival_time_histogram: need 1-D float64 times and int32 status")
+        n = t_end.shape[0]
+        h = torch.empty(bins, dtype=torch.int64, device=t_end.device)
+        _lib.arrival_histogram_device(t_end.device.index or 0, t_end.data_ptr(), t_end.stride(0) if n else 1,
+                                      status.data_ptr(), status.stride(0) if n else 1, n, t_min, t_max, bins,
+                                      h.data_ptr(), torch.cuda.current_stream(t_end.device).cuda_stream)
+    else:
+        import numpy as np
+        t = t_end[(status == 0) & ~torch.isnan(t_end)].numpy()
+        h = torch.from_numpy(np.histogram(t, bins=bins, range=(float(t_min), float(t_max)))[0].astype(np.int64))
     if reduce and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
     return h

@@ -578,6 +578,44 @@ def test_sharded_hip_compute_single_rank(lib):
     assert int(h.sum().item()) == int(((ref["status"] == 0) & (ref["end"][:, 0] >= 66) & (ref["end"][:, 0] <= 68)).sum())
 
 
+def test_arrival_time_histogram_equals_numpy(lib):
+    """pgr_arrival_histogram_device (BASELINE configs[4]) against np.histogram, count for count:
+    values on bin edges and on the range ends, NaN, dropped rays, strided views, packed end records."""
+    import torch
+    from pygenray_amd.distributed import arrival_time_histogram
+    rng = np.random.default_rng(4)
+    n, bins, lo, hi = 300_000, 4096, 660.0, 690.0
+    t = rng.uniform(lo - 2, hi + 2, n)
+    edges = np.linspace(lo, hi, bins + 1)
+    t[:5000] = rng.choice(edges, 5000)                        # exactly on edges, both range ends included
+    t[5000:5100] = np.nextafter(rng.choice(edges, 100), np.inf)
+    t[5100:5200] = np.nextafter(rng.choice(edges, 100), -np.inf)
+    t[5200:5300] = np.nan
+    st = np.where(rng.random(n) < 0.05, rng.integers(1, 6, n), 0).astype(np.int32)
+    want = np.histogram(t[(st == 0) & ~np.isnan(t)], bins=bins, range=(lo, hi))[0]
+    # (a) end-state layout [N][3], time in column 0: a strided view, read in place
+    end = torch.zeros(n, 3, dtype=torch.float64, device="cuda")
+    end[:, 0] = torch.from_numpy(t).cuda()
+    std = torch.from_numpy(st).cuda()
+    h = arrival_time_histogram(end[:, 0], std, bins, lo, hi)
+    assert h.dtype == torch.int64 and np.array_equal(h.cpu().numpy(), want)
+    # (b) the packed 40-byte end records of the multi-GPU path: T in slot 0, status in the low half of slot 4
+    rec = torch.zeros(n, 5, dtype=torch.float64, device="cuda")
+    rec[:, 0] = end[:, 0]
+    rec.view(torch.int32).view(n, 10)[:, 8] = std
+    h2 = arrival_time_histogram(rec[:, 0], rec.view(torch.int32).view(n, 10)[:, 8], bins, lo, hi)
+    assert np.array_equal(h2.cpu().numpy(), want)
+    # (c) few bins, empty input, argument errors
+    h3 = arrival_time_histogram(end[:, 0], std, 7, lo, hi)
+    assert np.array_equal(h3.cpu().numpy(), np.histogram(t[(st == 0) & ~np.isnan(t)], bins=7, range=(lo, hi))[0])
+    h4 = arrival_time_histogram(end[:0, 0], std[:0], 16, lo, hi)
+    assert h4.shape == (16,) and int(h4.sum()) == 0
+    with pytest.raises(lib.PgrError):
+        arrival_time_histogram(end[:, 0], std, 16, hi, lo)
+    with pytest.raises(lib.PgrError):
+        arrival_time_histogram(end[:, 0], std, 100_000, lo, hi)
+
+
 def test_wave_scheduler_is_a_pure_permutation(lib):
     """Cost-aware scheduling (placement, priorities, cost-sorted workgroups) only decides where
     and when a wave runs: for fan sizes around every regime boundary the results are bit-identical
