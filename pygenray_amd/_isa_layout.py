@@ -148,6 +148,8 @@ def relayout(asm_text, layout, only=None):
         j = k + 1
         items, where = [], []   # where[i] = line index of item i (instructions only)
         pos = 0                 # index into insts
+        pc_relative = False     # between s_getpc_b64 and the s_addc_u32 that completes the address:
+                                # the literal offsets count bytes from the s_getpc, sizes must not change
         while j < len(lines) and not lines[j].startswith(".Lfunc_end"):
             ln = lines[j]
             s = ln.strip()
@@ -167,7 +169,11 @@ def relayout(asm_text, layout, only=None):
                 mn_s, mn_o = s.split()[0], text.split()[0]
                 if re.sub(r"_e(32|64)$", "", mn_s) != re.sub(r"_e(32|64)$", "", mn_o):
                     raise RuntimeError(f"{name}: line {j}: '{mn_s}' does not match object '{mn_o}'")
-                items.append(("i", size, size == 4 and promotable(s))); where.append(j)
+                if mn_s == "s_getpc_b64":
+                    pc_relative = True
+                items.append(("i", size, size == 4 and not pc_relative and promotable(s))); where.append(j)
+                if mn_s == "s_addc_u32":
+                    pc_relative = False
                 pos += 1
             j += 1
         if pos != len(insts):
