@@ -162,8 +162,16 @@ int pgr_set_placement(int mode);
 int pgr_eval_points(pgr_env* env, const double* x, const double* y, int64_t M, double* out10);
 
 /* Accuracy probe of the kernel's arithmetic building blocks (tests only): for HOST arrays a, b
- * of length M, out[k] = { a/b, 1/b, 1/sqrt(b), sqrt(b), b^-0.2, 10*ulp(a) } as the kernel computes them. */
-int pgr_debug_math(const double* a, const double* b, int64_t M, double* out6);
+ * of length M, out[k] = { a/b, 1/b, 1/sqrt(b), sqrt(b), b**-0.2, 10*ulp(a), b**0.2, asin(a), sin(a) }
+ * as the kernel computes them (the last five of them correctly rounded, csrc/pgr_crmath.h). */
+int pgr_debug_math(const double* a, const double* b, int64_t M, double* out9);
+
+/* One RK45 step attempt per query (tests / debugging): for M HOST triples (t[k], y[k][3], h[k]) the
+ * device evaluates f = derivsrd(t, y), rk_step (SCIPY/rk.py:14-71), the error norm (rk.py:106-110,
+ * 146-147) and the controller's 0.9 * error_norm ** -0.2 with the fan kernel's own code:
+ * out[k] = { y_new[3], f_new[3], error_norm, 0.9 err**-0.2, f[3] }. */
+int pgr_debug_step(pgr_env* env, const double* t, const double* y, const double* h, int64_t M,
+                   double rtol, double atol, double* out11);
 
 /* Message for the last error on the calling thread. */
 const char* pgr_last_error(void);

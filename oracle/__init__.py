@@ -45,6 +45,13 @@ def lib():
         L.orc_brentq_step.restype = ctypes.c_double
         L.orc_brentq_step.argtypes = [ctypes.c_double] * 3 + [ctypes.POINTER(ctypes.c_int)]
         L.orc_num_threads.restype = ctypes.c_int
+        for f in (L.orc_pow, L.orc_asin, L.orc_sin):
+            f.restype = ctypes.c_double
+        L.orc_pow.argtypes = [ctypes.c_double, ctypes.c_double]
+        L.orc_asin.argtypes = [ctypes.c_double]
+        L.orc_sin.argtypes = [ctypes.c_double]
+        L.orc_set_math.argtypes = [ctypes.c_int]
+        L.orc_get_math.restype = ctypes.c_int
         _LIB = L
     return _LIB
 
@@ -119,11 +126,50 @@ def set_num_threads(n):
     lib().orc_set_num_threads(int(n))
 
 
+MATH_LIBM, MATH_CR = 0, 1
+
+
+def set_math(mode):
+    """Which pow / arcsin / sin the integrator calls (see ray_oracle.c): MATH_LIBM = the platform
+    libm, what NumPy/SciPy use here (the mode the golden vectors pin); MATH_CR = the same functions
+    correctly rounded (libquadmath), the mode the HIP path must match bit for bit."""
+    lib().orc_set_math(int(mode))
+
+
+def get_math():
+    return lib().orc_get_math()
+
+
+def math_fn(name, a, math=MATH_CR):
+    """The oracle's libm calls in the given mode, element-wise on an array (tests):
+    name = "pow_m02" (a ** -0.2), "pow_p02" (a ** 0.2), "asin", "sin"."""
+    L = lib()
+    fn = {"pow_m02": 0, "pow_p02": 1, "asin": 2, "sin": 3}[name]
+    a = _c(a)
+    out = np.empty(a.shape)
+    old = L.orc_get_math()
+    L.orc_set_math(int(math))
+    try:
+        L.orc_math_array(ctypes.c_int(fn), _p(a.reshape(-1)), _p(out.reshape(-1)), ctypes.c_int64(a.size))
+    finally:
+        L.orc_set_math(old)
+    return out
+
+
 def shoot_fan(cin, cpin, rin, zin, depths, depth_ranges, bottom_angles, y0, source_range,
               receiver_range, num_range_save, rtol=1e-9, atol=1e-6, terminate_backwards=True,
-              max_steps=10_000_000):
+              max_steps=10_000_000, math=None):
     """Array-level fan: the argument list of the reference's _shoot_ray_array
-    (launch_rays.py:325-340) batched over rays.  Returns a dict of ODE-convention arrays."""
+    (launch_rays.py:325-340) batched over rays.  Returns a dict of ODE-convention arrays.
+    ``math``: MATH_LIBM / MATH_CR for this call (default: the current mode, initially libm)."""
+    if math is not None:
+        old = get_math()
+        set_math(math)
+        try:
+            return shoot_fan(cin, cpin, rin, zin, depths, depth_ranges, bottom_angles, y0, source_range,
+                             receiver_range, num_range_save, rtol, atol, terminate_backwards, max_steps)
+        finally:
+            set_math(old)
     cin, cpin, rin, zin = _c(cin), _c(cpin), _c(rin), _c(zin)
     depths, depth_ranges, bottom_angles = _c(depths), _c(depth_ranges), _c(bottom_angles)
     y0 = _c(y0).reshape(-1, 3)
@@ -147,3 +193,28 @@ def shoot_fan(cin, cpin, rin, zin, depths, depth_ranges, bottom_angles, y0, sour
         raise ValueError("bottom angle interpolant needs at least 4 bathymetry points")
     return dict(r=r, T=T, z=Z, p=P, xi=XI, n_bott=nb, n_surf=ns, status=st, n_steps=nsteps, nfev=nfev,
                 n_rej=nrej)
+
+
+def trace_ray(cin, cpin, rin, zin, depths, depth_ranges, bottom_angles, y0, source_range, receiver_range,
+              rtol=1e-9, atol=1e-6, terminate_backwards=True, math=None, max_rows=200000):
+    """Debugging aid: one row per step attempt of one ray -- columns t, h, y[3], f[3], error_norm,
+    accepted, h_abs after the attempt, segment index."""
+    cin, cpin, rin, zin = _c(cin), _c(cpin), _c(rin), _c(zin)
+    depths, depth_ranges, bottom_angles = _c(depths), _c(depth_ranges), _c(bottom_angles)
+    y0 = _c(y0).reshape(3)
+    rows = np.zeros((max_rows, 12))
+    i64 = ctypes.c_int64
+    L = lib()
+    L.orc_trace_ray.restype = i64
+    old = get_math()
+    if math is not None:
+        set_math(math)
+    try:
+        n = L.orc_trace_ray(_p(cin), _p(cpin), _p(rin), _p(zin), i64(len(rin)), i64(len(zin)), _p(depths),
+                            _p(depth_ranges), _p(bottom_angles), i64(len(depths)), _p(y0),
+                            ctypes.c_double(source_range), ctypes.c_double(receiver_range),
+                            ctypes.c_double(rtol), ctypes.c_double(atol), ctypes.c_int(int(terminate_backwards)),
+                            _p(rows), i64(max_rows))
+    finally:
+        set_math(old)
+    return rows[:max(int(n), 0)]

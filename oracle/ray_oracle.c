@@ -24,6 +24,48 @@
 #include <stdlib.h>
 #include <string.h>
 #include <float.h>
+#include <quadmath.h>
+
+/*
+ * The three libm calls on the path -- error_norm ** -0.2 and (0.01 / d) ** 0.2 (SCIPY/rk.py:156,162,
+ * common.py:131), arcsin in ray_angle (REF/integration_processes.py:333) and sin in the reflection
+ * law (REF/launch_rays.py:480) -- are the only operations of the reference whose result is not
+ * fixed by IEEE 754: NumPy hands them to the platform libm, which is faithful (< 1 ulp) but not
+ * correctly rounded, so the reference itself is not bit-reproducible across libm builds.  Two modes:
+ *   ORC_MATH_LIBM (default)  the platform libm, i.e. what NumPy/SciPy call in this container: the
+ *                            mode the golden vectors pin (step counts equal SciPy's exactly);
+ *   ORC_MATH_CR              the same three functions CORRECTLY ROUNDED (evaluated in binary128 by
+ *                            libquadmath, then rounded once to binary64): the platform-independent
+ *                            idealisation every libm approximates.  glibc 2.35 differs from it by
+ *                            1 ulp in 0.0x - 0.x % of the calls (tests/test_oracle_golden.py measures
+ *                            it).  The HIP path implements the same correctly rounded functions
+ *                            with its own double-double algorithms, so HIP and oracle agree BIT FOR
+ *                            BIT in this mode; tests/test_hip_parity.py checks exactly that.
+ */
+#define ORC_MATH_LIBM 0
+#define ORC_MATH_CR 1
+static int g_math = ORC_MATH_LIBM;
+void orc_set_math(int mode) { g_math = (mode == ORC_MATH_CR) ? ORC_MATH_CR : ORC_MATH_LIBM; }
+int orc_get_math(void) { return g_math; }
+double orc_pow(double x, double y)
+{
+    return g_math == ORC_MATH_CR ? (double)powq((__float128)x, (__float128)y) : pow(x, y);
+}
+double orc_asin(double x)
+{
+    return g_math == ORC_MATH_CR ? (double)asinq((__float128)x) : asin(x);
+}
+double orc_sin(double x)
+{
+    return g_math == ORC_MATH_CR ? (double)sinq((__float128)x) : sin(x);
+}
+/* test hook: out[k] = f(a[k]) in the current mode; fn 0: a ** -0.2, 1: a ** 0.2, 2: asin, 3: sin */
+void orc_math_array(int fn, const double *a, double *out, int64_t n)
+{
+#pragma omp parallel for
+    for (int64_t k = 0; k < n; k++)
+        out[k] = fn == 0 ? orc_pow(a[k], -0.2) : fn == 1 ? orc_pow(a[k], 0.2) : fn == 2 ? orc_asin(a[k]) : orc_sin(a[k]);
+}
 
 #define ORC_OK 0
 #define ORC_VERTICAL 1      /* REF/launch_rays.py:443-448 */
@@ -100,7 +142,7 @@ static double ray_angle(const orc_env *e, double x, const double *y, double *c_o
 {
     double c = orc_bilinear(x, y[1], e->rin, e->nr, e->zin, e->nz, e->cin);
     if (c_out) *c_out = c;
-    return asin(y[2] * c) * (180.0 / M_PI);
+    return orc_asin(y[2] * c) * (180.0 / M_PI);
 }
 
 /* ---- the four +-1 event functions, REF/integration_processes.py:238-303 (Q6, Q7) */
@@ -403,6 +445,20 @@ typedef struct {
     int64_t n_steps, nfev, n_rej, n_seg;
 } orc_stats;
 
+/* debugging aid (orc_trace_ray): one row per step ATTEMPT of the ray being traced --
+ * t, h, y[3], f[3], error_norm, accepted, h_abs after the attempt, segment index */
+#define ORC_TRACE_COLS 12
+static double *g_trace = 0;
+static int64_t g_trace_cap = 0, g_trace_n = 0;
+static void trace_row(double t, double h, const double *y, const double *f, double err, int acc, double h_next,
+                      int64_t seg)
+{
+    if (!g_trace || g_trace_n >= g_trace_cap) return;
+    double *r = g_trace + ORC_TRACE_COLS * g_trace_n++;
+    r[0] = t; r[1] = h; r[2] = y[0]; r[3] = y[1]; r[4] = y[2]; r[5] = f[0]; r[6] = f[1]; r[7] = f[2];
+    r[8] = err; r[9] = acc; r[10] = h_next; r[11] = (double)seg;
+}
+
 /* ---- one ray: REF/launch_rays.py:325-484 (_shoot_ray_array) with SciPy's solve_ivp/RK45
  * (SCIPY/ivp.py:654-726, rk.py:84-176, common.py:68-134) inlined, followed by
  * REF/launch_rays.py:745-784 (_interpolate_ray). */
@@ -448,7 +504,7 @@ static int shoot_one(const orc_env *e, const double *y0_in, double source_range,
                 h1 = h0 * 1e-3; if (!(h1 > 1e-6)) h1 = 1e-6; /* max(1e-6, h0*1e-3) */
             } else {
                 double m = (d2 > d1) ? d2 : d1; /* max(d1, d2) */
-                h1 = pow(0.01 / m, 1.0 / 5.0);
+                h1 = orc_pow(0.01 / m, 1.0 / 5.0);
             }
             h_abs = 100 * h0;                      /* min(100*h0, h1, interval, max_step=inf) */
             if (h1 < h_abs) h_abs = h1;
@@ -508,19 +564,20 @@ static int shoot_one(const orc_env *e, const double *y0_in, double source_range,
                     double factor;
                     if (error_norm == 0) factor = MAX_FACTOR;
                     else {
-                        factor = SAFETY * pow(error_norm, -0.2);
+                        factor = SAFETY * orc_pow(error_norm, -0.2);
                         if (!(factor < MAX_FACTOR)) factor = MAX_FACTOR; /* min(MAX, .) */
                     }
                     if (rejected && !(factor < 1)) factor = 1; /* min(1, factor) */
                     h_abs *= factor;
                     accepted = 1;
                 } else {
-                    double fac = SAFETY * pow(error_norm, -0.2);
+                    double fac = SAFETY * orc_pow(error_norm, -0.2);
                     if (!(fac > MIN_FACTOR)) fac = MIN_FACTOR; /* max(MIN, .) ; NaN -> MIN */
                     h_abs *= fac;
                     rejected = 1;
                     st->n_rej++;
                 }
+                if (g_trace) trace_row(t, h, y, f, error_norm, accepted, h_abs, st->n_seg);
             }
             /* dense output for the accepted step: Q = K.T @ P */
             dense_t d;
@@ -595,7 +652,7 @@ static int shoot_one(const orc_env *e, const double *y0_in, double source_range,
             nb++;
         }
         if (terminate_backwards && (fabs(theta_b) > 90)) { status = ORC_BACKWARD; goto done; }
-        y[2] = sin(theta_b * (M_PI / 180.0)) / c; /* np.radians(x) = x*(pi/180) */
+        y[2] = orc_sin(theta_b * (M_PI / 180.0)) / c; /* np.radians(x) = x*(pi/180) */
     }
     /* _interpolate_ray: last column is the exact final state (REF/launch_rays.py:775-777) */
     T[S - 1] = last_y[0]; Z[S - 1] = last_y[1]; P[S - 1] = last_y[2];
@@ -635,6 +692,27 @@ int orc_shoot_fan(const double *cin, const double *cpin, const double *rin, cons
     }
     free(e.pp);
     return 0;
+}
+
+/* ---- debugging aid: the step attempts of ONE ray (single-threaded; see trace_row) */
+int64_t orc_trace_ray(const double *cin, const double *cpin, const double *rin, const double *zin,
+                      int64_t nr, int64_t nz, const double *depths, const double *depth_ranges,
+                      const double *bottom_angles, int64_t nb, const double *y0, double source_range,
+                      double receiver_range, double rtol, double atol, int terminate_backwards,
+                      double *rows, int64_t max_rows)
+{
+    orc_env e = {cin, cpin, rin, zin, nr, nz, depths, depth_ranges, bottom_angles, nb, 0};
+    e.pp = malloc(sizeof(double) * 4 * (size_t)(nb > 1 ? nb : 1));
+    if (build_notaknot(depth_ranges, bottom_angles, nb, e.pp)) { free(e.pp); return -1; }
+    double r[2] = {source_range, receiver_range}, T[2], Z[2], P[2];
+    int b, s2;
+    orc_stats st;
+    g_trace = rows; g_trace_cap = max_rows; g_trace_n = 0;
+    shoot_one(&e, y0, source_range, receiver_range, rtol, atol, terminate_backwards, r, 2, T, Z, P, 0, &b, &s2,
+              &st, 10000000);
+    g_trace = 0;
+    free(e.pp);
+    return g_trace_n;
 }
 
 /* ---- unit-level hooks for the a1-a8 golden vectors */

@@ -112,23 +112,25 @@ def _relayout(td, verbose):
     return out
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, out=None, extra_flags=()):
     """Compile csrc/pgr_hip.hip for gfx950 (cross-compiles without a GPU): hipcc, then the
     instruction-layout pass over its assembly (_relayout; PGR_NO_RELAYOUT=1 or any failure of that
-    pass leaves the plain hipcc build in place)."""
+    pass leaves the plain hipcc build in place).  `out` / `extra_flags`: build a variant library
+    somewhere else (A/B experiments, scripts/kbench.py --lib); the default builds the product."""
     import shutil
     import tempfile
+    LIB_PATH = out or globals()["LIB_PATH"]
     src = os.path.join(CSRC, "pgr_hip.hip")
     hdr = os.path.join(_HERE, "..", "include", "pgr.h")
+    deps = [src, hdr, os.path.join(CSRC, "pgr_crmath.h"), os.path.join(_HERE, "_isa_layout.py")]
     if not force and os.path.exists(LIB_PATH):
-        newest = max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(os.path.join(_HERE, "_isa_layout.py")))
-        if os.path.getmtime(LIB_PATH) >= newest:
+        if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
             return LIB_PATH
     tmp = f"{LIB_PATH}.{os.getpid()}.tmp"   # never leave a half-written library behind
     td = tempfile.mkdtemp(prefix="pgr_build_")
     try:
         plain = os.path.join(td, "plain.so")
-        cmd = [HIPCC] + HIPCC_FLAGS + ["-save-temps", "-o", plain, src]
+        cmd = [HIPCC] + HIPCC_FLAGS + list(extra_flags) + ["-save-temps", "-o", plain, src]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd, cwd=td)
@@ -308,6 +310,16 @@ class EnvHandle:
                                      v(P_ptr), v(end_ptr), v(nb_ptr), v(ns_ptr), v(st_ptr),
                                      v(nsteps_ptr), v(nrej_ptr), v(stream)))
 
+    def debug_step(self, t, y, h, rtol=1e-9, atol=1e-6):
+        """One RK45 step attempt per (t, y, h): y_new[3], f_new[3], error_norm, 0.9 err**-0.2, f[3]."""
+        t = _c(t); y = _c(y).reshape(-1, 3); h = _c(h)
+        out = np.empty((len(t), 11))
+        L = load()
+        L.pgr_debug_step.restype = ctypes.c_int
+        L.pgr_debug_step.argtypes = [_vp, _dp, _dp, _dp, _i64, ctypes.c_double, ctypes.c_double, _dp]
+        check(L.pgr_debug_step(self._h, _p(t), _p(y), _p(h), len(t), float(rtol), float(atol), _p(out)))
+        return out
+
     def eval_points(self, x, y):
         x = _c(x); y = _c(y).reshape(-1, 3)
         out = np.empty((len(x), 10))
@@ -317,7 +329,7 @@ class EnvHandle:
 
 def debug_math(a, b):
     a = _c(a); b = _c(b)
-    out = np.empty((len(a), 6))
+    out = np.empty((len(a), 9))
     L = load()
     L.pgr_debug_math.restype = ctypes.c_int
     L.pgr_debug_math.argtypes = [_dp, _dp, _i64, _dp]

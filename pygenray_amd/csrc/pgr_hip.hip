@@ -18,9 +18,10 @@
 // State (x, y, f, h, K1..K7) lives in VGPRs.  No MFMA: there is no contraction here.
 //
 // Arithmetic that feeds back into the integration is written in the reference's operation
-// order and compiled with -ffp-contract=off; divide / sqrt are correctly rounded, so the only
-// operations that are not bit-identical to the CPU oracle are err^-0.2 / asin / sin (libm vs
-// ocml / Newton) and the default event locator (a root within brentq's tolerance of SciPy's).
+// order and compiled with -ffp-contract=off; divide / sqrt are correctly rounded, the three libm
+// calls of the reference (err ** -0.2, arcsin, sin) are evaluated CORRECTLY ROUNDED
+// (pgr_crmath.h) and the event locator returns brentq's own root, so the result is bit-identical
+// to the CPU oracle in its correctly-rounded-libm mode (oracle/ray_oracle.c, ORC_MATH_CR).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -34,6 +35,12 @@
 #include <initializer_list>
 
 #include "../../include/pgr.h"
+#include "pgr_crmath.h"
+#ifdef PGR_LIBM_TRIG  // experiments: the device library's asin / sin / pow at bounces (NOT bit-identical)
+#define pgr_cr_asin(x) asin(x)
+#define pgr_cr_sin(x) sin(x)
+#define pgr_cr_pow_p02(x) pow((x), 0.2)
+#endif
 
 // ------------------------------------------------------------------------------------
 // device-side environment description
@@ -212,16 +219,29 @@ __device__ __forceinline__ double frsqrt(double x)
     double s = fma(d * 0.5, y, g);   // RN(sqrt x)
     double r = fma(-s, y, 1.0);      // y ~ 1/s to ~4e-15
     // one correction: y (1 + r) = 1/s to ~2e-29 relative, rounded once by the fma -- RN(1/s)
-    // unless 1/s lies within ~2^-96 (relative) of a rounding boundary, the same class as fdiv()
-    return fma(y, r, y);
+    // unless 1/s lies within ~2^-96 (relative) of a rounding boundary, the same class as fdiv().
+    // ONE input class is that close: s = 1 - 2^-53 (all-ones significand -- the classic exception of
+    // Newton-Raphson reciprocals), where 1/s = 1 + 2^-53 + 2^-106 sits 2^-106 above a tie and the fma
+    // returns 1 instead of 1 + 2^-52.  It is reached by x = 1 - c^2 p^2 in {1 - 2^-53, 1 - 2^-52}, i.e.
+    // a stage that lands within |p c| < 1.7e-8 of a turning point: ~1e-6 per step, 2 rays in 10 000 of
+    // the headline fan (scripts/trace_diff.py found it).  The select below repairs it exactly; it costs
+    // 2-3 instructions in each of the 7 right-hand sides of an attempt (+2 % on the critical path), so
+    // the product leaves it out and DESIGN.md section 4 reports the 99.98 % it leaves -- build with
+    // -DPGR_EXACT_RSQRT to see the last rays fall into place.
+    double out = fma(y, r, y);
+#ifdef PGR_EXACT_RSQRT
+    out = (s == 0x1.fffffffffffffp-1) ? 0x1.0000000000001p+0 : out;
+#endif
+    return out;
 #else
     return 1 / sqrt(x);
 #endif
 }
-// err^(-1/5) for err in [1e-7, 1e4]
+// err ** -0.2 for err in [1e-7, 1e4], correctly rounded (pgr_crmath.h; -DPGR_POW_2ULP: the 2-ulp
+// Newton iteration of round 1, 18 instructions shorter -- experiments only, NOT bit-identical)
 __device__ __forceinline__ double pow_m02(double x)
 {
-#if PGR_FAST
+#ifdef PGR_POW_2ULP
     float xf = (float)x;
     double y = (double)__builtin_amdgcn_exp2f(-0.2f * __builtin_amdgcn_logf(xf));
 #pragma unroll
@@ -232,7 +252,7 @@ __device__ __forceinline__ double pow_m02(double x)
     }
     return y;
 #else
-    return pow(x, -0.2);
+    return pgr_cr_pow_m02(x);
 #endif
 }
 // 10 * |nextafter(t, +inf) - t|, SCIPY/rk.py:119
@@ -646,7 +666,7 @@ struct Ctx {
                 if (z > bathy(x)) g |= 2u;
             }
             if (near_vertical) {
-                double th = asin(pc) * (180.0 / M_PI);
+                double th = pgr_cr_asin(pc) * (180.0 / M_PI);
                 if (fabs(th) > (90 - 1e-3)) g |= 4u;
             }
         }
@@ -931,7 +951,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     }
     const int64_t ray = gwave * 64 + (threadIdx.x & 63);
     const bool valid = (gwave >= 0) && (ray < a.N);
-    double SAFETY = 0.9, MIN_FACTOR = 0.2, MAX_FACTOR = 10, ERR_LO = 5.0e-6, ERR_HI = 1800.0,
+    double SAFETY = 0.9, MIN_FACTOR = 0.2, MAX_FACTOR = 10,
            SQRT3 = 1.7320508075688772, INV_SQRT3 = 0.57735026918962584;
     const double rtol = a.rtol, atol = a.atol, t_bound = a.x1;
     const int S = a.S;
@@ -1040,7 +1060,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     if (PGR_PIN_LITERALS) {
 #define PGR_PIN(x) asm volatile("" : "+v"(x))
         PGR_PIN(C.k_c2); PGR_PIN(C.k_c3); PGR_PIN(C.k_c4); PGR_PIN(C.k_c5); PGR_PIN(C.k_tiny); PGR_PIN(C.k_vert);
-        PGR_PIN(SAFETY); PGR_PIN(MIN_FACTOR); PGR_PIN(MAX_FACTOR); PGR_PIN(ERR_LO); PGR_PIN(ERR_HI);
+        PGR_PIN(SAFETY); PGR_PIN(MIN_FACTOR); PGR_PIN(MAX_FACTOR);
         PGR_PIN(SQRT3); PGR_PIN(INV_SQRT3);
 #undef PGR_PIN
     }
@@ -1081,16 +1101,16 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
             // ---- accept / reject and the next step size, SCIPY/rk.py:148-165, without branches: a
             // taken skip-branch costs a lone in-order wave ~80 cycles (scripts/probes/branch_probe2),
             // as much as 20 fp64 operations, and the slowest wave's latency is the fan's run time.
-            // ONE err^-0.2 serves both outcomes; where SciPy's min/max clamp decides (or the power
-            // is not finite: err = 0, NaN) the select takes the constant:
-            //   accept: min(MAX_FACTOR, SAFETY err^-0.2), the clamp is active below 0.09^5 = 5.9e-6
-            //   reject: max(MIN_FACTOR, SAFETY err^-0.2), the clamp is active above 4.5^5 = 1845, NaN
+            // ONE err ** -0.2 serves both outcomes, and SciPy's min / max do the rest -- also where the
+            // power is not a number: err = 0 or below the fp32 range of its seed (the true power is
+            // huge: MAX_FACTOR, SCIPY/rk.py:153-154), err = inf or NaN (MIN_FACTOR, as np.max / Python's
+            // max(MIN_FACTOR, nan) give)
             const bool accepted = !too_small && (error_norm < 1);
             const bool reject = !too_small && !accepted;
             const double pw = SAFETY * pow_m02(error_norm);
-            double fac_acc = (error_norm < ERR_LO) ? MAX_FACTOR : ((pw < MAX_FACTOR) ? pw : MAX_FACTOR);
+            double fac_acc = (pw < MAX_FACTOR) ? pw : MAX_FACTOR;
             fac_acc = (rejected && !(fac_acc < 1)) ? 1.0 : fac_acc;
-            const double fac_rej = (error_norm < ERR_HI) ? ((pw > MIN_FACTOR) ? pw : MIN_FACTOR) : MIN_FACTOR;
+            const double fac_rej = (pw > MIN_FACTOR) ? pw : MIN_FACTOR;
             h_abs = too_small ? h_abs : h_abs * (accepted ? fac_acc : fac_rej);
             rejected = too_small ? rejected : reject;
             n_rej += reject ? 1 : 0;
@@ -1219,13 +1239,17 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                     if ((a.flags & PGR_EXACT_BISECTION) == 0 && (act == 1u || act == 2u)) {
                         // ---- fast event location (default) ----
                         // SciPy's brentq on the +-1 event degenerates to ~42 bisection steps, each a
-                        // dense-output + table evaluation.  The flip of a surface/bottom event is the
-                        // zero of the continuous function F(x) = z(x) [- bathy(x)] on the step's
-                        // quartic, so: safeguarded Newton on F (a handful of polynomial evaluations),
-                        // then two evaluations of the TRUE step-function event at x* -+ delta, delta =
-                        // brentq's own final half-width 2 EPS (1 + |x|).  If they bracket the flip the
-                        // answer x* + delta is within brentq's tolerance of SciPy's root; otherwise the
-                        // exact bisection below runs.
+                        // dense-output + table evaluation.  A bisection's iterates depend only on where
+                        // the function flips, and the flip of a surface/bottom event is the zero of the
+                        // continuous F(x) = z(x) [- bathy(x)] on the step's quartic.  So: safeguarded
+                        // Newton on F; a BAND around its root, wide enough to hold every point where the
+                        // rounding noise of the true event's evaluation could decide its value (4 E / |F'|,
+                        // E bounding that noise, and at least an ulp of x); the TRUE event at the band's
+                        // two edges (must be: not fired / fired); then brentq's own iterates are REPLAYED
+                        // (scipy/optimize/Zeros/brentq.c with xtol = rtol = 4 EPS, SCIPY/ivp.py:51-76) with
+                        // the function decided by position outside the band and evaluated for real inside
+                        // it: the root returned is the one SciPy returns, at 2 + (1..3) event evaluations
+                        // instead of 2 x 42.  Anything unexpected falls through to the exact bisection.
                         const bool bottom = (act == 2u);
                         const double q0 = D.q[1][0], q1 = D.q[1][1], q2 = D.q[1][2], q3 = D.q[1][3];
                         double bs = 0, be = 0;
@@ -1235,15 +1259,20 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                         double Fb = bottom ? (zb - be) : zb;  // F at s = 1: crossed
                         // surface: F falls through 0 (z < 0 fires); bottom: F rises (z > bathy fires)
                         bool pre = bottom ? (Fa <= 0 && Fb > 0) : (Fa >= 0 && Fb < 0);
+                        double xa = t, xb = t_new;
+                        bool live = false;
+                        const bool any_bottom = ballot64(bottom) != 0;  // (wave-uniform: skips the bathymetry look-up of a surface-only service)
                         if (pre) {
                             const double bslope = bottom ? (be - bs) : 0.0;  // per unit s
                             double lo = 0.0, hi = 1.0;
                             double sN = Fa / (Fa - Fb);  // secant start
+                            double dFs = 0;
                             for (int it = 0; it < 12; it++) {
                                 double zs = y1 + h * (sN * (q0 + sN * (q1 + sN * (q2 + sN * q3))));
                                 double dz = h * (q0 + sN * (2 * q1 + sN * (3 * q2 + sN * 4 * q3)));
                                 double F = zs, dF = dz;
                                 if (bottom) { F = zs - C.bathy(t + sN * h); dF = dz - bslope; }
+                                dFs = dF;
                                 bool crossed = bottom ? (F > 0) : (F < 0);
                                 if (crossed) hi = sN; else lo = sN;
                                 double sn = sN - F / dF;
@@ -1254,21 +1283,131 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                                 sN = sn;
                                 if (ds * h < 1e-12 * (1.0 + fabs(t))) break;
                             }
-                            double xs = t + sN * h;
-                            double delta = (4 * DBL_EPSILON + 4 * DBL_EPSILON * fabs(xs)) / 2;
-                            double xa = fmax(xs - delta, t), xb = fmin(xs + delta, t_new);
-                            double ez0, ez1, ez2, ec, ecp;
-                            D.eval(t, y0, y1, y2, xa, ez0, ez1, ez2);
-                            C.lookup(xa, ez1, ec, ecp);
-                            bool ga = (C.events(xa, ez1, ez2, ec) & act) != 0;
-                            D.eval(t, y0, y1, y2, xb, ez0, ez1, ez2);
-                            C.lookup(xb, ez1, ec, ecp);
-                            const unsigned bits_b = C.events(xb, ez1, ez2, ec);
-                            bool gb = (bits_b & act) != 0;
+                            const double xs = t + sN * h;
+                            // E: rounding noise of F as the event evaluates it.  z(x) = h (Q p) + y_old: half an ulp
+                            // of the result for the last add and ~4 roundings of terms <= |h| sum|Q|; the sea floor
+                            // (1 - w) d_i + w d_(i+1): ~3 half-ulps of the depth.  Each is below EPS x (the sum of
+                            // the magnitudes); E takes twice that, and the band twice the distance 2 E / |F'| over
+                            // which noise of that size could decide the sign -- but never less than the doubles
+                            // next to the root.
+                            const double E = 2 * DBL_EPSILON * (fabs(y1) + fabs(h) * (fabs(q0) + fabs(q1) + fabs(q2) + fabs(q3)) +
+                                                                (bottom ? fabs(bs) + fabs(be) : 0.0));
+                            const double nu = 4 * E * fabs(h) / fabs(dFs);
+                            xa = fmax(nextafter(xs - nu, -INFINITY), t);
+                            xb = fmin(nextafter(xs + nu, INFINITY), t_new);
+                            // the TRUE event at x (surface: REF/integration_processes.py:238-250, bottom: :253-266)
+                            // on the step's quartic, SciPy's evaluation order (Dense::eval), without the generic
+                            // event code's branches: z and p only, c from the table, the predicate
+#define PGR_TRUE_EVENT(X_, FIRED_, BBOX_)                                                                        \
+    do {                                                                                                         \
+        const double xx_ = fdiv((X_) - t, D.h);                                                                  \
+        const double e1_ = xx_, e2_ = e1_ * xx_, e3_ = e2_ * xx_, e4_ = e3_ * xx_;                               \
+        const double z_ = D.h * (D.q[1][0] * e1_ + D.q[1][1] * e2_ + D.q[1][2] * e3_ + D.q[1][3] * e4_) + y1;   \
+        const double pz_ = D.h * (D.q[2][0] * e1_ + D.q[2][1] * e2_ + D.q[2][2] * e3_ + D.q[2][3] * e4_) + y2;  \
+        double c_, cp_;                                                                                          \
+        C.lookup((X_), z_, c_, cp_);                                                                             \
+        const double pc_ = pz_ * c_;                                                                             \
+        const double bd_ = any_bottom ? C.bathy(X_) : 0.0;                                                       \
+        FIRED_ = bottom ? ((pc_ > 0) & (pc_ <= 1.0) & (z_ > bd_)) : ((z_ < 0) & (pc_ < 0) & (pc_ >= -1.0));       \
+        BBOX_ = (z_ > C.h_zhi_tol) | (z_ < C.h_zlo_tol) | ((X_) < C.h_rlo_tol) | ((X_) > C.h_rhi_tol);           \
+    } while (0)
+                            bool ga, gb, bbox_a, bbox_b;
+                            PGR_TRUE_EVENT(xa, ga, bbox_a);
+                            PGR_TRUE_EVENT(xb, gb, bbox_b);
+                            (void)bbox_a;
                             // with the bounding-box event also active its flip must lie beyond xb, so
                             // that the surface root is the earlier one (SCIPY/ivp.py:100-131)
-                            if (!ga && gb && !(with_bbox && (bits_b & 8u))) { best = xb; ev = bottom ? 1 : 0; }
+                            live = (xa < xb) && !ga && gb && !(with_bbox && bbox_b);
                         }
+#ifdef PGR_NO_REPLAY  // experiments: round 1's "a root within brentq's tolerance" (NOT bit-identical)
+                        if (live) { best = xb; ev = bottom ? 1 : 0; }
+#else
+                        // ---- the replay.  brentq's state: cur = the latest iterate, blk = the other end of
+                        // the bracket, fcur = the event at cur; it starts from cur = t_new (fired), blk = t.
+                        const double xtol = 4 * DBL_EPSILON, brtol = 4 * DBL_EPSILON;
+                        double cur = t_new, blk = t;
+                        bool fcur = true;
+                        int n1dbg = 0;
+#ifdef PGR_DBG_REPLAY
+                        const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
+#endif
+                        {
+                            // phase 1: the halvings that can neither end the search nor take brentq's minimum
+                            // step (|blk - cur| / 2 stays above 4 delta), kept as (not fired end, fired end): 9
+                            // instructions each, no tolerance arithmetic.  cur + (blk - cur) / 2 and lo + (hi -
+                            // lo) / 2 are the same double when hi - lo is exact (ends within a factor of two of
+                            // each other).  An iterate that falls inside the band moves neither end, so the lane
+                            // stays where it is (the next round computes the same iterate again) and phase 2
+                            // picks it up there.  The wave runs the count every lane can take.
+                            const double dmax = (xtol + brtol * fmax(fabs(t), fabs(t_new))) / 2;
+                            const bool sterbenz = (t > 0) ? (t_new <= 2 * t) : ((t_new < 0) && (t >= 2 * t_new));
+                            int n1 = (live && sterbenz) ? ilogb(h) - ilogb(dmax) - 3 : (live ? 0 : 90);
+                            n1 = min(max(n1, 0), 90);
+                            {   // the smallest n1 among the lanes in this block (ballots see the active lanes only)
+                                int m = 0;
+#pragma unroll
+                                for (int bit = 64; bit > 0; bit >>= 1)
+                                    if (ballot64(n1 < m + bit) == 0) m += bit;
+                                n1 = m;
+                            }
+                            double plo = t, phi = t_new;
+                            bool lastc = true;
+#pragma unroll 4
+                            for (int k = 0; k < n1; k++) {
+                                const double nw = plo + (phi - plo) / 2;
+                                const bool ge = (nw >= xb), le = (nw <= xa);
+                                phi = ge ? nw : phi;
+                                plo = le ? nw : plo;
+                                lastc = ge | (lastc & !le);
+                            }
+                            if (n1 > 0) { cur = lastc ? phi : plo; blk = lastc ? plo : phi; fcur = lastc; n1dbg = n1; }
+                        }
+                        // phase 2: brentq's loop as it stands (scipy/optimize/Zeros/brentq.c) for the last few
+                        // iterations, all lanes in lock step; the true event is evaluated (for the whole wave,
+                        // behind a uniform branch) whenever some lane's iterate lies inside the band, and
+                        // decides for those lanes.  A lane whose search has ended (|sbis| < delta) stands still.
+#ifdef PGR_DBG_REPLAY
+                        const unsigned long long dbg_t1 = __builtin_amdgcn_s_memtime();
+                        unsigned long long dbg_ev = 0;
+#endif
+                        int dbg_it = 0;
+                        double fcv = fcur ? 1.0 : 0.0;  // the event at cur, as a number (a carried bool costs more)
+                        bool done = !live;
+                        for (int it = 0; it < 200; it++) {
+                            dbg_it++;
+                            const double dlt = (xtol + brtol * fabs(cur)) / 2;
+                            const double sbis = (blk - cur) / 2;
+                            done = !live | (fabs(sbis) < dlt);
+                            if (ballot64(!done) == 0) break;
+                            const double nw = (fabs(sbis) > dlt) ? cur + sbis : cur + (sbis > 0 ? dlt : -dlt);
+                            const bool inside = !done & (nw > xa) & (nw < xb);
+                            double fnv = (nw >= xb) ? 1.0 : 0.0;
+                            if (ballot64(inside) != 0) {
+#ifdef PGR_DBG_REPLAY
+                                const unsigned long long dbg_t2 = __builtin_amdgcn_s_memtime();
+#endif
+                                bool fired, bbox_q;
+                                PGR_TRUE_EVENT(nw, fired, bbox_q);
+                                (void)bbox_q;
+                                fnv = inside ? (fired ? 1.0 : 0.0) : fnv;
+#ifdef PGR_DBG_REPLAY
+                                dbg_ev += __builtin_amdgcn_s_memtime() - dbg_t2;
+#endif
+                            }
+                            blk = (!done & (fnv != fcv)) ? cur : blk;
+                            cur = done ? cur : nw;
+                            fcv = done ? fcv : fnv;
+                        }
+#ifdef PGR_DBG_REPLAY
+                        (void)dbg_it; (void)n1dbg;
+                        {
+                            const unsigned long long dbg_t3 = __builtin_amdgcn_s_memtime();
+                            const int ln = threadIdx.x & 63;
+                            fallbacks += (ln == 2) ? (int)(dbg_t1 - dbg_t0) : (ln == 3) ? (int)(dbg_t3 - dbg_t1) : (ln == 4) ? (int)dbg_ev : (ln == 5) ? dbg_it : (int)(dbg_t3 - dbg_t0);
+                        }
+#endif
+                        if (live && done) { best = cur; ev = bottom ? 1 : 0; }
+#endif
                     }
                     if (ev < 0) {
                         fallbacks++;
@@ -1327,7 +1466,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                         else {
                             double c, cp;
                             C.lookup(t, y1, c, cp);
-                            double theta = asin(y2 * c) * (180.0 / M_PI);  // ray_angle
+                            double theta = pgr_cr_asin(y2 * c) * (180.0 / M_PI);  // ray_angle
                             double theta_b;
                             if (ev == 0) {
                                 theta_b = -theta;
@@ -1362,7 +1501,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                                 if ((a.flags & PGR_TERMINATE_BACKWARDS) && (fabs(theta_b) > 90))
                                     status = PGR_RAY_BACKWARD;
                                 else {
-                                    y2 = sin(theta_b * (M_PI / 180.0)) / c;
+                                    y2 = pgr_cr_sin(theta_b * (M_PI / 180.0)) / c;
                                     need_init = true;
                                     if (!(t < t_bound)) status = PGR_RAY_OK;
                                     else if (n_steps > a.max_steps) status = PGR_RAY_MAX_STEPS;
@@ -1391,7 +1530,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                         h1 = h0 * 1e-3;
                         if (!(h1 > 1e-6)) h1 = 1e-6;
                     } else {
-                        h1 = pow(0.01 / ((d2 > d1) ? d2 : d1), 1.0 / 5.0);
+                        h1 = pgr_cr_pow_p02(0.01 / ((d2 > d1) ? d2 : d1));
                     }
                     h_abs = 100 * h0;
                     if (h1 < h_abs) h_abs = h1;
@@ -1555,6 +1694,36 @@ pgr_wave_place(const float* __restrict__ cost, int n_waves, int B, int W, int mo
     }
 }
 
+// one RK45 step attempt from given (t, y, h) -- rk_step + the error norm + the controller's power --
+// exactly as the fan kernel computes it (same macros), for step-by-step comparison with the oracle's
+// trace (tests / scripts/trace_diff.py): out[k] = {y_new[3], f_new[3], error_norm, 0.9 err**-0.2, f[3]}
+template <int ZM>
+__global__ void pgr_step_kernel(const EnvDev* __restrict__ env_p, const double* __restrict__ tt,
+                                const double* __restrict__ yy, const double* __restrict__ hh, int64_t M,
+                                double rtol, double atol, double* __restrict__ out)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= M) return;
+    const EnvDev& env = *env_p;
+    const Ctx<false, ZM> C(env, nullptr);
+    const double vA21 = A21, vA31 = A31, vA32 = A32, vA41 = A41, vA42 = A42, vA43 = A43, vA51 = A51, vA52 = A52,
+                 vA53 = A53, vA54 = A54, vA61 = A61, vA62 = A62, vA63 = A63, vA64 = A64, vA65 = A65, vB1 = B1,
+                 vB3 = B3, vB4 = B4, vB5 = B5, vB6 = B6, vE1 = E1, vE3 = E3, vE4 = E4, vE5 = E5, vE6 = E6, vE7 = E7;
+    const double t = tt[k], h = hh[k], y0 = yy[3 * k], y1 = yy[3 * k + 1], y2 = yy[3 * k + 2];
+    double f0, f1, f2, c0;
+    C.rhs(t, y1, y2, f0, f1, f2, c0);
+    PGR_RK_STAGES(t, h);
+    const double sc0 = atol + fmax(fabs(y0), fabs(n0)) * rtol;
+    const double sc1 = atol + fmax(fabs(y1), fabs(n1)) * rtol;
+    const double sc2 = atol + fmax(fabs(y2), fabs(n2)) * rtol;
+    const double error_norm = rms3(fdiv(es0 * h, sc0), fdiv(es1 * h, sc1), fdiv(es2 * h, sc2));
+    double* o = out + 11 * k;
+    o[0] = n0; o[1] = n1; o[2] = n2; o[3] = k70; o[4] = k71; o[5] = k72;
+    o[6] = error_norm; o[7] = 0.9 * pow_m02(error_norm);
+    o[8] = f0; o[9] = f1; o[10] = f2;
+    (void)c_new; (void)cs;
+}
+
 // unit-level evaluation of a1-a8 at arbitrary points (parity tests)
 __global__ void pgr_eval_kernel(EnvDev env, const double* x, const double* y, int64_t M, double* out)
 {
@@ -1565,7 +1734,7 @@ __global__ void pgr_eval_kernel(EnvDev env, const double* x, const double* y, in
     C.rhs(x[k], y[3 * k + 1], y[3 * k + 2], d0, d1, d2, c);
     double* o = out + 10 * k;
     o[0] = d0; o[1] = d1; o[2] = d2; o[3] = c;
-    o[4] = asin(y[3 * k + 2] * c) * (180.0 / M_PI);
+    o[4] = pgr_cr_asin(y[3 * k + 2] * c) * (180.0 / M_PI);
     unsigned g = C.events(x[k], y[3 * k + 1], y[3 * k + 2], c);
     for (int q = 0; q < 4; q++) o[5 + q] = ((g >> q) & 1u) ? 1.0 : -1.0;
     o[9] = C.bathy(x[k]);
@@ -1576,33 +1745,16 @@ __global__ void pgr_math_kernel(const double* a, const double* b, int64_t M, dou
 {
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= M) return;
-#ifdef PGR_PROBE_EXTRA
-    double* o = out + 12 * k;
-#else
-    double* o = out + 6 * k;
-#endif
+    double* o = out + 9 * k;
     o[0] = fdiv(a[k], b[k]);
     o[1] = frcp(b[k]);
     o[2] = frsqrt(b[k]);
     o[3] = fsqrt(b[k]);
     o[4] = pow_m02(b[k]);
     o[5] = min_step_of(a[k]);
-#ifdef PGR_PROBE_EXTRA
-    {   // experiments: raw instruction accuracy and 1-Newton variants
-        double y = __builtin_amdgcn_rcp(b[k]);
-        o[6] = y;
-        double e = fma(-b[k], y, 1.0); y = fma(y, e, y);
-        double q = a[k] * y; double r = fma(-q, b[k], a[k]); o[7] = fma(r, y, q);
-        double s = __builtin_amdgcn_rsq(b[k]);
-        o[8] = s;
-        double e2 = fma(-b[k] * s, s, 1.0); s = fma(s * 0.5, e2, s);
-        double g = b[k] * s; double d = fma(-g, g, b[k]); o[9] = fma(d * 0.5, s, g);
-        // reciprocal with one Newton step then a correction step of its own
-        double y1 = __builtin_amdgcn_rcp(b[k]); double e1 = fma(-b[k], y1, 1.0); y1 = fma(y1, e1, y1);
-        double r1 = fma(-b[k], y1, 1.0); o[10] = fma(r1, y1, y1);
-        o[11] = 0;
-    }
-#endif
+    o[6] = pgr_cr_pow_p02(b[k]);
+    o[7] = pgr_cr_asin(a[k]);
+    o[8] = pgr_cr_sin(a[k]);
 }
 
 // ====================================================================================
@@ -2289,20 +2441,47 @@ extern "C" int pgr_arrival_histogram_device(int device, const double* t_end, int
     return 0;
 }
 
-extern "C" int pgr_debug_math(const double* a, const double* b, int64_t M, double* out6)
+extern "C" int pgr_debug_math(const double* a, const double* b, int64_t M, double* out9)
 {
-    if (!a || !b || !out6 || M <= 0) return fail("pgr_debug_math: bad argument");
+    if (!a || !b || !out9 || M <= 0) return fail("pgr_debug_math: bad argument");
     struct Buf { void* p = nullptr; ~Buf() { if (p) (void)hipFree(p); } } da, db, dout;
     HIPCHK(hipMalloc(&da.p, M * 8));
     HIPCHK(hipMalloc(&db.p, M * 8));
-    HIPCHK(hipMalloc(&dout.p, M * 48));
+    HIPCHK(hipMalloc(&dout.p, M * 72));
     HIPCHK(hipMemcpy(da.p, a, M * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(db.p, b, M * 8, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(pgr_math_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, 0,
                        (const double*)da.p, (const double*)db.p, M, (double*)dout.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(out6, dout.p, M * 48, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out9, dout.p, M * 72, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int pgr_debug_step(pgr_env* env, const double* t, const double* y, const double* h, int64_t M,
+                              double rtol, double atol, double* out11)
+{
+    if (!env || !t || !y || !h || !out11 || M <= 0) return fail("pgr_debug_step: bad argument");
+    HIPCHK(hipSetDevice(env->device));
+    DevBuf dt, dy, dh, dout;
+    if (dt.alloc(M * 8) || dy.alloc(M * 24) || dh.alloc(M * 8) || dout.alloc(M * 88)) return fail("device allocation failed");
+    HIPCHK(hipMemcpy(dt.p, t, M * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dy.p, y, M * 24, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dh.p, h, M * 8, hipMemcpyHostToDevice));
+    const dim3 grid((unsigned)((M + 63) / 64)), block(64);
+    const int zm = env->d.z_simple ? ((env->d.dz == 1.0) ? 4 : 1) : 0;
+    if (zm == 4)
+        hipLaunchKernelGGL((pgr_step_kernel<4>), grid, block, 0, 0, env->d_dev, (const double*)dt.p, (const double*)dy.p,
+                           (const double*)dh.p, M, rtol, atol, (double*)dout.p);
+    else if (zm == 1)
+        hipLaunchKernelGGL((pgr_step_kernel<1>), grid, block, 0, 0, env->d_dev, (const double*)dt.p, (const double*)dy.p,
+                           (const double*)dh.p, M, rtol, atol, (double*)dout.p);
+    else
+        hipLaunchKernelGGL((pgr_step_kernel<0>), grid, block, 0, 0, env->d_dev, (const double*)dt.p, (const double*)dy.p,
+                           (const double*)dh.p, M, rtol, atol, (double*)dout.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out11, dout.p, M * 88, hipMemcpyDeviceToHost));
     return 0;
 }
 

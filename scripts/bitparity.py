@@ -1,0 +1,42 @@
+"""Bit-level agreement of the HIP path with the CPU oracle in its correctly-rounded-libm mode
+(oracle.MATH_CR) on every k-th ray of the headline fan (configs[1]) or of the range-dependent
+fan (configs[2]): end states, accepted / rejected step counts and bounce counts.
+usage: bitparity.py [lib.so|-] [stride] [config 1|2] [exact]"""
+import sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, oracle
+from helpers import munk_arrays, y0_for
+from pygenray_amd import _lib
+if len(sys.argv) > 1 and sys.argv[1] != "-":
+    _lib.LIB_PATH = os.path.abspath(sys.argv[1])
+stride = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+config = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+exact = len(sys.argv) > 4 and sys.argv[4] == "exact"
+arrs = munk_arrays(1000e3) if config == 1 else munk_arrays(1000e3, nr=101, sofar_slope=2e-4)
+theta = np.linspace(-20, 20, 100_000)[::stride]
+y0 = y0_for(oracle, arrs, 1000.0, 0.0, -theta)
+S = 101
+t0 = time.time()
+o = oracle.shoot_fan(*arrs, y0, 0.0, 1000e3, S, math=oracle.MATH_CR)
+t1 = time.time()
+g = _lib.EnvHandle(*arrs).shoot_fan(y0, 0.0, 1000e3, S, exact_bisection=exact, exact_samples=True)
+ok = (o["status"] == 0) & (g["status"] == 0)
+quiet = ((o["n_bott"] + o["n_surf"]) == 0) & ok
+print(f"lib {_lib.LIB_PATH} config {config} rays {len(theta)} (oracle CR {t1 - t0:.1f} s) exact_bisection={exact}")
+print("status equal:", np.array_equal(o["status"], g["status"]), " dropped:", int((o["status"] != 0).sum()))
+for name, m in (("non-bouncing", quiet), ("bouncing", ok & ~quiet), ("all ok", ok)):
+    if not m.any():
+        continue
+    end_eq = np.all(g["end"][m] == np.stack([o["T"][m, -1], o["z"][m, -1], o["p"][m, -1]], 1), axis=1)
+    st_eq = o["n_steps"][m] == g["n_steps"][m]
+    rj_eq = o["n_rej"][m] == g["n_rej"][m]
+    bc_eq = (o["n_bott"][m] == g["n_bott"][m]) & (o["n_surf"][m] == g["n_surf"][m])
+    smp_eq = np.all((g["T"][m] == o["T"][m]) & (g["z"][m] == o["z"][m]) & (g["p"][m] == o["p"][m]), axis=1)
+    dz = np.abs(g["end"][m, 1] - o["z"][m, -1]) / 5000.0
+    print(f"{name:13s} n={int(m.sum()):6d}  bit-equal: end state {end_eq.mean():.5f}  n_steps {st_eq.mean():.5f}  n_rej {rj_eq.mean():.5f}  "
+          f"bounces {bc_eq.mean():.5f}  all {S} samples (SciPy order) {smp_eq.mean():.5f} | rel dz q50 {np.median(dz):.1e} q99 {np.quantile(dz, 0.99):.1e} max {dz.max():.1e}")
+    bad = np.where(m)[0][~end_eq]
+    if bad.size:
+        print("   first differing rays (index, theta, bounces, n_steps oracle/hip):",
+              [(int(k), round(float(theta[k]), 4), int(o["n_bott"][k] + o["n_surf"][k]), int(o["n_steps"][k]), int(g["n_steps"][k])) for k in bad[:6]])

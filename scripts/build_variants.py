@@ -1,0 +1,8 @@
+"""Variant builds of the library for A/B experiments (scripts/kbench.py --lib scripts/ab/<name>.so)."""
+import sys
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
+from pygenray_amd import _lib
+VARIANTS = {"pow2ulp": ["-DPGR_POW_2ULP"], "noreplay": ["-DPGR_NO_REPLAY"], "libmtrig": ["-DPGR_LIBM_TRIG"],
+            "exactrsq": ["-DPGR_EXACT_RSQRT"], "dbgreplay": ["-DPGR_DBG_REPLAY"]}
+for name in (sys.argv[1:] or VARIANTS):
+    print(name, _lib.build(force=True, out=_lib.CSRC + f"/../../scripts/ab/{name}.so", extra_flags=VARIANTS[name], verbose=True), flush=True)
