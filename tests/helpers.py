@@ -6,25 +6,33 @@ import numpy as np
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ENV_KEYS = ["cin", "cpin", "rin", "zin", "depths", "depth_ranges", "bottom_angles"]
 
-# Parity policy (DESIGN.md "Parity").  north_star: (r, z, tau) within REL_TOL relative of the
-# CPU reference, relative to the field scale (water-column depth for z, arrival time for T,
-# 1/c for p; r is exact).  The reference integrator is, however, chaotic at the last bit: the
-# embedded error estimate is a near-cancelling sum whose rounding noise (1e-8 relative) is fed
-# back into every later step size, so a 1-ulp change of ANY input (p0, rtol, the result of
-# pow) moves a random ~10 % of the rays -- bouncing or not -- by up to millimetres at 1000 km
-# while the rest agree to 1e-10 (measured with the reference itself, golden g3, and with the
-# oracle below).  So a ray passes if its deviation is
-#   <= REL_TOL x scale                                 (the north-star bound), or
-#   <= NOISE_FACTOR x its own spread over the oracle's 1-ulp perturbed runs, or
-#   <= ENSEMBLE_FACTOR x the largest such spread among rays of its class (bouncing / not),
-# and, so that the ensemble clause cannot hide a systematic error, the MEDIAN deviation of the
-# rays that never touch a boundary must meet REL_TOL itself (when there are >= 8 of them).
-# Samples the reference itself produces by extrapolating a quartic more than XI_MAX step
-# lengths (Q5) are only required to exist, not to agree.
+# Parity policy.  Two comparisons, two rules:
+#
+# (A) HIP vs the CPU oracle in its correctly-rounded-libm mode (oracle.MATH_CR) -- the parity test
+#     proper: BIT-IDENTICAL status, bounce counts, accepted / rejected step counts, end states and
+#     (with PGR_EXACT_SAMPLES) every saved sample, Q5 extrapolated ones included: assert_bit_parity.
+#     One input class of the kernel's 1/sqrt is not correctly rounded (s = 1 - 2^-53, reached within
+#     |p c| < 1.7e-8 of a turning point, ~1e-6 per step): at most MAX_ODD_FRACTION of the
+#     rays (and at least one, so that a small test cannot fail on a single such ray) may differ, and
+#     those must still be within ODD_REL_TOL.
+#
+# (B) HIP (or the oracle) vs vectors produced by the REFERENCE itself (tests/golden): the reference's
+#     NumPy / SciPy arithmetic is not reproducible to the bit outside its own process (BLAS dot
+#     products fuse and reorder, libm is faithful but not correctly rounded) and its adaptive
+#     controller amplifies a last-bit change chaotically, so this comparison is statistical:
+#     a ray passes if its deviation is <= REL_TOL x scale (north_star: (r, z, tau) within 1e-8
+#     relative; scale = water-column depth for z, arrival time for T, 1/c for p; r is exact) or
+#     <= NOISE_FACTOR x its OWN spread over the oracle's 1-ulp perturbed runs; and the MEDIAN
+#     deviation of each class of rays -- never touching a boundary / bouncing -- must meet REL_TOL
+#     itself (classes of >= 8 rays; `strict_bouncing=False` for the coarse or kinked grids on which
+#     the reference's own test tolerances apply, abs_floor).  No class-wide allowance.
+#     Samples the reference produces by extrapolating a quartic more than XI_MAX step lengths (Q5)
+#     amplify rounding by xi^4 and are compared with a tolerance scaled by that.
 REL_TOL = 1e-8
 NOISE_FACTOR = 20.0
-ENSEMBLE_FACTOR = 3.0
 XI_MAX = 8.0
+MAX_ODD_FRACTION = 1e-3
+ODD_REL_TOL = 1e-5
 
 
 def load(name):
@@ -77,8 +85,48 @@ def oracle_selfnoise(oracle, arrs, y0, x0, x1, S, **kw):
     return outs
 
 
-def assert_fan_parity(test, ref, noise_runs=None, scales=None, label="", abs_floor=None):
-    """test/ref: dicts with T,z,p (N,S), n_bott, n_surf, status; ref also has xi."""
+def assert_bit_parity(test, ref, label="", samples=True, max_odd=None):
+    """(A): test (HIP) against ref (oracle.MATH_CR run of the same inputs), bit for bit.  `samples`:
+    also every saved sample (the HIP fan was shot with exact_samples=True); otherwise the samples a
+    step evaluates inside itself (0 <= xi <= 1, stage-major FMA form by default) may differ by
+    rounding (1e-12 x scale) and all others must still be equal."""
+    assert np.array_equal(test["status"], ref["status"]), \
+        f"{label}: status differs at {np.where(test['status'] != ref['status'])[0][:10]}"
+    ok = ref["status"] == 0
+    for k in ("n_bott", "n_surf"):
+        assert np.array_equal(test[k][ok], ref[k][ok]), f"{label}: {k}"
+    for nm in "Tzp":
+        assert np.array_equal(np.isnan(test[nm]), np.isnan(ref[nm])), f"{label}: NaN pattern of {nm}"
+    if not ok.any():
+        return dict(n=0, odd=0)
+    end_ref = np.stack([ref["T"][:, -1], ref["z"][:, -1], ref["p"][:, -1]], 1)
+    same = np.all(test["end"] == end_ref, axis=1) | ~ok
+    same &= (test["n_steps"].astype(np.int64) == ref["n_steps"]) | ~ok
+    if test.get("n_rej") is not None and ref.get("n_rej") is not None:
+        same &= (test["n_rej"].astype(np.int64) == ref["n_rej"]) | ~ok
+    xi = ref["xi"]
+    inside = (xi >= 0) & (xi <= 1)
+    inside[:, -1] = False
+    for nm, scale in (("T", max(float(np.nanmax(np.abs(ref["T"][ok]))), 1e-9)), ("z", max(float(np.nanmax(np.abs(ref["z"][ok]))), 1.0)),
+                      ("p", 1.0 / 1400.0)):
+        eq = (test[nm] == ref[nm]) | np.isnan(ref[nm])
+        if not samples:
+            with np.errstate(invalid="ignore"):
+                eq |= inside & (np.abs(test[nm] - ref[nm]) <= 1e-12 * scale)
+        same &= np.all(eq, axis=1) | ~ok
+    odd = np.where(~same)[0]
+    n = int(ok.sum())
+    allowed = max(1, int(np.ceil(MAX_ODD_FRACTION * n))) if max_odd is None else max_odd
+    assert len(odd) <= allowed, (f"{label}: {len(odd)} of {n} rays are not bit-identical to the oracle "
+                                 f"(allowed {allowed}); first {odd[:8]}")
+    for k in odd:   # the odd ones out: the same ray all the same (DESIGN.md section 4)
+        for j, scale in enumerate((max(float(end_ref[k, 0]), 1e-9), max(float(np.nanmax(np.abs(ref["z"][ok]))), 1.0), 1 / 1400.0)):
+            assert abs(test["end"][k, j] - end_ref[k, j]) <= ODD_REL_TOL * scale, (label, int(k), j)
+    return dict(n=n, odd=len(odd))
+
+
+def assert_fan_parity(test, ref, noise_runs=None, scales=None, label="", abs_floor=None, strict_bouncing=True):
+    """(B): test/ref: dicts with T,z,p (N,S), n_bott, n_surf, status; ref also has xi."""
     assert np.array_equal(test["status"], ref["status"]), \
         f"{label}: status differs at {np.where(test['status'] != ref['status'])[0][:10]}"
     ok = ref["status"] == 0
@@ -88,20 +136,25 @@ def assert_fan_parity(test, ref, noise_runs=None, scales=None, label="", abs_flo
         assert np.array_equal(np.isnan(test[nm]), np.isnan(ref[nm])), f"{label}: NaN pattern of {nm}"
     if not ok.any():
         return {}
-    good = np.abs(ref["xi"]) <= XI_MAX
+    xi = np.abs(ref["xi"])
     if noise_runs is not None:
         # a bounce a hair to the other side of a save point flips which quartic owns the
-        # sample (Q5): only samples that are interior in every oracle run are compared
+        # sample (Q5): the largest |xi| over the oracle runs prices the sample
         for nr_ in noise_runs:
             if nr_.get("xi") is not None:
-                good &= np.abs(nr_["xi"]) <= XI_MAX
+                xi = np.maximum(xi, np.abs(nr_["xi"]))
+    good = xi <= XI_MAX
     good[:, -1] = True
+    # Q5 samples: a quartic extrapolated xi step lengths amplifies rounding by xi^4
+    amp = np.where(good, 1.0, np.minimum(np.maximum(xi, 1.0) ** 4, 1e12))
+    amp[:, -1] = 1.0
     zscale, tscale, pscale = scales if scales else (5000.0, np.nanmax(ref["T"][ok]), 1.0 / 1500.0)
     quiet = ((ref["n_bott"] + ref["n_surf"]) == 0)[ok]
     worst = {}
     for nm, scale in (("T", tscale), ("z", zscale), ("p", pscale)):
-        d = np.abs(test[nm] - ref[nm])
-        d = np.nan_to_num(np.where(good, d, 0.0)[ok], nan=np.inf).max(1)       # per ray
+        dfull = np.abs(test[nm] - ref[nm]) / amp
+        d = np.nan_to_num(np.where(good, dfull, 0.0)[ok], nan=np.inf).max(1)       # per ray, interior samples
+        dq5 = np.nan_to_num(np.where(good, 0.0, dfull)[ok], nan=np.inf).max(1)      # per ray, Q5 samples / xi^4
         tol = np.full(d.shape[0], REL_TOL * scale)
         if abs_floor is not None:  # coarse-grid cases: the reference's own test tolerances
             tol = np.maximum(tol, abs_floor[nm])
@@ -114,17 +167,16 @@ def assert_fan_parity(test, ref, noise_runs=None, scales=None, label="", abs_flo
                 s[~okn] = np.inf
                 spread = np.maximum(spread, s)
             tol = np.maximum(tol, NOISE_FACTOR * spread)
-            for cls in (quiet, ~quiet):
-                fin = cls & np.isfinite(spread)
-                if fin.any():
-                    tol[cls] = np.maximum(tol[cls], ENSEMBLE_FACTOR * spread[fin].max())
         bad = d > tol
         worst[nm] = float(np.nanmax(d) / scale)
         assert not bad.any(), (f"{label}: {nm} differs: worst {np.nanmax(d):.3e} (rel {worst[nm]:.2e}), "
                                f"{bad.sum()} rays beyond tolerance, first {np.where(bad)[0][:5]}")
-        if quiet.sum() >= 8:
-            med = float(np.median(d[quiet]))
-            floor = REL_TOL * scale if abs_floor is None else max(REL_TOL * scale, abs_floor[nm])
-            assert med <= floor, f"{label}: median {nm} deviation of non-bouncing rays {med:.3e} > {floor:.3e}"
-            worst[nm + "_median_quiet"] = med / scale
+        badq = dq5 > np.maximum(tol, 1e-6 * scale)
+        assert not badq.any(), f"{label}: extrapolated (Q5) samples of {nm} differ beyond xi^4 x tolerance: rays {np.where(badq)[0][:5]}"
+        floor = REL_TOL * scale if abs_floor is None else max(REL_TOL * scale, abs_floor[nm])
+        for cls, name in ((quiet, "non-bouncing"), (~quiet, "bouncing")):
+            if cls.sum() >= 8 and (name == "non-bouncing" or strict_bouncing):
+                med = float(np.median(d[cls]))
+                assert med <= floor, f"{label}: median {nm} deviation of {name} rays {med:.3e} > {floor:.3e}"
+                worst[nm + "_median_" + name] = med / scale
     return worst

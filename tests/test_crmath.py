@@ -1,0 +1,86 @@
+"""The correctly rounded pow / asin / sin of the HIP path (pygenray_amd/csrc/pgr_crmath.h), checked
+WITHOUT a GPU: the header's host twin (tests/crmath_host.c, built here with gcc) against the oracle's
+binary128 evaluation (libquadmath) rounded once.  The device build of the same text is checked
+against the same reference in tests/test_hip_parity.py::test_arithmetic_building_blocks."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def crh(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("crmath") / "libcrmath_host.so")
+    subprocess.check_call(["gcc", "-O2", "-std=gnu99", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+                           "-fopenmp", "-Wno-unknown-pragmas", "-o", so, os.path.join(HERE, "crmath_host.c"), "-lm"])
+    L = ctypes.CDLL(so)
+    dp = ctypes.POINTER(ctypes.c_double)
+
+    def ev(fn, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        out = np.empty_like(a)
+        L.crh_eval(ctypes.c_int(fn), a.ctypes.data_as(dp), out.ctypes.data_as(dp), ctypes.c_int64(a.size))
+        return out
+    return ev
+
+
+N = 2_000_000
+
+
+def test_pow_of_the_step_controller_is_correctly_rounded(crh):
+    rng = np.random.default_rng(0)
+    x = np.exp(rng.uniform(np.log(1e-7), np.log(1e4), N))          # error norms (SCIPY/rk.py:156,162)
+    assert np.array_equal(crh(0, x), oracle.math_fn("pow_m02", x))
+    # the error norms a step controller actually produces crowd around 0.1 ... 1
+    x = rng.uniform(0.02, 1.2, N)
+    assert np.array_equal(crh(0, x), oracle.math_fn("pow_m02", x))
+    # what falls outside the fp32 range of the seed is decided by SciPy's min / max anyway
+    assert not np.isfinite(crh(0, np.array([0.0])))[0] or crh(0, np.array([0.0]))[0] > 10
+    # select_initial_step's (0.01 / max(d1, d2)) ** 0.2: d > 1e-15, so the argument stays below 1e13
+    v = np.exp(rng.uniform(np.log(1e-15), np.log(1e13), N))
+    assert np.array_equal(crh(1, v), oracle.math_fn("pow_p02", v))
+
+
+def test_asin_and_sin_are_correctly_rounded(crh):
+    rng = np.random.default_rng(1)
+    v = np.concatenate([rng.uniform(-1, 1, N // 2), rng.uniform(-1, 1, N // 4) ** 5,            # p c of any ray
+                        np.sign(rng.uniform(-1, 1, N // 4)) * (1 - 10 ** rng.uniform(-16, -0.3, N // 4)),  # near vertical
+                        [0.0, -0.0, 1.0, -1.0, 0.75, -0.75, 0.5, 2.0 ** -30, 5e-324]])
+    assert np.array_equal(crh(2, v), oracle.math_fn("asin", v))
+    assert np.all(np.signbit(crh(2, np.array([-0.0, 0.0]))) == [True, False])
+    assert np.all(np.isnan(crh(2, np.array([1.0000000000000002, -3.0, np.nan]))))             # Q7
+    w = np.concatenate([rng.uniform(-6.5, 6.5, N // 2), rng.uniform(-1.6, 1.6, N // 4), rng.uniform(-1, 1, N // 4) ** 7,
+                        np.pi / 2 * np.arange(-4, 5), np.pi / 4 * np.arange(-8, 9), [0.0, -0.0, 1e-300]])
+    assert np.array_equal(crh(3, w), oracle.math_fn("sin", w))
+
+
+def test_the_platform_libm_is_faithful_but_not_correctly_rounded():
+    """Why bit-identity needs the correctly rounded functions on BOTH sides: glibc's pow / asin /
+    sin (what NumPy and SciPy call in this container, and the oracle's default MATH_LIBM mode)
+    differ from the correctly rounded value in about one call in a thousand, by one ulp."""
+    rng = np.random.default_rng(2)
+    x = np.exp(rng.uniform(np.log(1e-6), np.log(2e3), 400_000))
+    v = rng.uniform(-0.9, 0.9, 400_000)
+    for name, arg in (("pow_m02", x), ("asin", v), ("sin", v * 1.7)):
+        cr = oracle.math_fn(name, arg, math=oracle.MATH_CR)
+        lm = oracle.math_fn(name, arg, math=oracle.MATH_LIBM)
+        diff = cr != lm
+        assert 1e-5 < diff.mean() < 1e-2, (name, diff.mean())
+        assert np.all(np.abs(cr[diff] - lm[diff]) <= np.spacing(np.abs(cr[diff])))
+    # ... which moves few rays, since a step's h = (t + h_abs) - t is quantised to ulp(t): the two
+    # modes integrate most rays identically and the rest within the 1-ulp noise class
+    import helpers
+    arrs = helpers.munk_arrays(300e3)
+    y0 = helpers.y0_for(oracle, arrs, 1000.0, 0.0, np.linspace(-20, 20, 96))
+    a = oracle.shoot_fan(*arrs, y0, 0.0, 300e3, 31, math=oracle.MATH_LIBM)
+    b = oracle.shoot_fan(*arrs, y0, 0.0, 300e3, 31, math=oracle.MATH_CR)
+    assert np.array_equal(a["status"], b["status"]) and np.array_equal(a["n_bott"], b["n_bott"])
+    assert np.mean(a["n_steps"] == b["n_steps"]) > 0.9
+    d = np.abs(a["z"][:, -1] - b["z"][:, -1]) / 5000.0
+    assert np.median(d) < 1e-9 and d.max() < 1e-5

@@ -9,7 +9,7 @@ import pytest
 
 import oracle
 from helpers import (load, env_from, tiled_env, munk, munk_arrays, y0_for, assert_fan_parity,
-                     oracle_selfnoise, XI_MAX)
+                     assert_bit_parity, oracle_selfnoise, XI_MAX)
 
 pytestmark = pytest.mark.gpu
 
@@ -22,21 +22,22 @@ def lib():
     return _lib
 
 
-def gpu_vs_oracle(lib, arrs, y0, x0, x1, S, label, abs_floor=None, scales=None, **kw):
+def gpu_vs_oracle(lib, arrs, y0, x0, x1, S, label, max_odd=None, **kw):
+    """The parity test proper: the HIP fan against the oracle in its correctly-rounded-libm mode,
+    BIT FOR BIT -- status, bounce counts, accepted and rejected step counts, end states and every
+    saved sample in SciPy's evaluation order (Q5 extrapolated ones included); the default sample
+    form (stage-major FMAs inside a step) within 1e-12 of them."""
     env = lib.EnvHandle(*arrs)
-    g = env.shoot_fan(y0, x0, x1, S, **kw)
-    o = oracle.shoot_fan(*arrs, y0, x0, x1, S, **kw)
-    noise = oracle_selfnoise(oracle, arrs, y0, x0, x1, S, **kw)
-    if scales is None:
-        scales = (float(arrs[3][-1]), max(float(np.nanmax(np.where(np.isnan(o["T"]), 0, o["T"]))), 1e-9), 1 / 1500.0)
-    worst = assert_fan_parity(g, o, noise_runs=noise, scales=scales, label=label, abs_floor=abs_floor)
+    o = oracle.shoot_fan(*arrs, y0, x0, x1, S, math=oracle.MATH_CR, **kw)
+    g = env.shoot_fan(y0, x0, x1, S, exact_samples=True, **kw)
+    stats = assert_bit_parity(g, o, label=label, max_odd=max_odd)
+    g2 = env.shoot_fan(y0, x0, x1, S, **kw)
+    assert_bit_parity(g2, o, label=label + " (default sample form)", samples=False, max_odd=max_odd)
     ok = o["status"] == 0
-    dsteps = np.abs(g["n_steps"][ok].astype(np.int64) - o["n_steps"][ok])
-    assert np.all(dsteps <= np.maximum(2, 0.04 * o["n_steps"][ok])), dsteps.max()
     # the last column is the exact final state and equals end_state
     assert np.array_equal(g["end"][ok, 1], g["z"][ok, -1])
     env.close()
-    return g, o, worst
+    return g, o, stats
 
 
 # ------------------------------------------------------------------ unit level: a1-a8 on the device
@@ -61,10 +62,13 @@ def test_device_unit_vectors(lib):
 
 
 # ------------------------------------------------------------------ golden fans (reference outputs)
-def golden_check(lib, g, arrs, x0, x1, S, prefix="", label="", abs_floor=None, **kw):
+def golden_check(lib, g, arrs, x0, x1, S, prefix="", label="", abs_floor=None, strict_bouncing=True, **kw):
+    """HIP against vectors the REFERENCE itself produced (statistical policy (B) of helpers.py) and,
+    on the same inputs, against the oracle bit for bit (A)."""
     env = lib.EnvHandle(*arrs)
-    out = env.shoot_fan(g[prefix + "y0"], x0, x1, S, **kw)
-    o = oracle.shoot_fan(*arrs, g[prefix + "y0"], x0, x1, S, **kw)  # for xi + noise only
+    out = env.shoot_fan(g[prefix + "y0"], x0, x1, S, exact_samples=True, **kw)
+    o = oracle.shoot_fan(*arrs, g[prefix + "y0"], x0, x1, S, math=oracle.MATH_CR, **kw)
+    assert_bit_parity(out, o, label=label + " vs oracle")
     ok = g[prefix + "ok"].astype(bool)
     ref = dict(T=g[prefix + "T"], z=g[prefix + "z"], p=g[prefix + "p"], n_bott=g[prefix + "n_bott"],
                n_surf=g[prefix + "n_surf"], status=np.where(ok, 0, -1), xi=o["xi"])
@@ -75,7 +79,7 @@ def golden_check(lib, g, arrs, x0, x1, S, prefix="", label="", abs_floor=None, *
         n["status"] = np.where(n["status"] == 0, 0, -1)
     assert_fan_parity(test, ref, noise_runs=noise,
                       scales=(float(arrs[3][-1]), float(np.nanmax(ref["T"])), 1 / 1500.0), label=label,
-                      abs_floor=abs_floor)
+                      abs_floor=abs_floor, strict_bouncing=strict_bouncing)
     env.close()
     return out
 
@@ -94,8 +98,8 @@ def test_golden_irregular_range_bathymetry_and_depth_grids(lib):
     at rtol 1e-9 and at 1e-5 (steps wider than several range cells)."""
     g = load("g9_irregular_grids.npz")
     arrs = env_from(g)
-    golden_check(lib, g, arrs, 1e3, 69e3, 61, prefix="t9_", rtol=1e-9, label="g9 rtol 1e-9")
-    out = golden_check(lib, g, arrs, 1e3, 69e3, 61, prefix="t5_", rtol=1e-5, label="g9 rtol 1e-5")
+    golden_check(lib, g, arrs, 1e3, 69e3, 61, prefix="t9_", rtol=1e-9, label="g9 rtol 1e-9", strict_bouncing=False)
+    out = golden_check(lib, g, arrs, 1e3, 69e3, 61, prefix="t5_", rtol=1e-5, label="g9 rtol 1e-5", strict_bouncing=False)
     assert np.array_equal(out["n_steps"], g["t5_n_steps"])
     assert np.array_equal(out["n_bott"], g["t5_n_bott"]) and np.array_equal(out["n_surf"], g["t5_n_surf"])
 
@@ -113,10 +117,10 @@ def test_golden_range_dependent_and_mirrored(lib):
     g = load("g4_range_dependent.npz")
     arrs = env_from(g)
     floor = dict(T=1e-6, z=1e-2, p=1e-7)  # the reference's own tolerances on this coarse grid
-    golden_check(lib, g, arrs, 10e3, 90e3, 81, prefix="fwd_", label="g4 fwd", abs_floor=floor)
+    golden_check(lib, g, arrs, 10e3, 90e3, 81, prefix="fwd_", label="g4 fwd", abs_floor=floor, strict_bouncing=False)
     arrs_m = [np.ascontiguousarray(arrs[0][::-1]), np.ascontiguousarray(arrs[1][::-1]), -arrs[2][::-1],
               arrs[3], np.ascontiguousarray(arrs[4][::-1]), -arrs[5][::-1], -arrs[6][::-1]]
-    golden_check(lib, g, arrs_m, -60e3, -10e3, 80, prefix="bwd_", label="g4 bwd", abs_floor=floor)
+    golden_check(lib, g, arrs_m, -60e3, -10e3, 80, prefix="bwd_", label="g4 bwd", abs_floor=floor, strict_bouncing=False)
 
 
 def test_golden_config2_subset(lib):
@@ -131,7 +135,7 @@ def test_golden_const_c_steep_linear_flatearth(lib):
     g = load("g5_const_c_steep.npz")
     golden_check(lib, g, env_from(g), 0.0, 1.5e3, 31, rtol=float(g["rtol"]), label="steep")
     g = load("g5_flatearth.npz")
-    golden_check(lib, g, env_from(g), 0.0, 100e3, 101, label="flat earth (non-uniform zin)")
+    golden_check(lib, g, env_from(g), 0.0, 100e3, 101, label="flat earth (non-uniform zin)", strict_bouncing=False)
 
 
 def test_reference_fixture_through_dropin_api(lib):
@@ -160,14 +164,8 @@ def test_fan_vs_oracle_munk_lds_path(lib):
     arrs = munk_arrays(200e3)
     theta = np.linspace(-20, 20, 333)  # ragged: not a multiple of 64
     y0 = y0_for(oracle, arrs, 1000.0, 0.0, theta)
-    g, o, worst = gpu_vs_oracle(lib, arrs, y0, 0.0, 200e3, 201, "munk 200 km")
-    # rays that never touch a boundary: 1e-8 relative without appeal to the noise floor for
-    # all but the few that graze a boundary (a grazing turning point amplifies last-bit
-    # differences of pow() in the step controller; those stay within the policy above)
-    quiet = (o["n_bott"] + o["n_surf"]) == 0
-    err = np.abs(g["z"][quiet] - o["z"][quiet]).max(1) / 5000
-    assert np.quantile(err, 0.95) < 1e-8 and err.max() < 1e-6
-    assert np.mean(g["n_steps"][quiet] == o["n_steps"][quiet]) > 0.9
+    g, o, stats = gpu_vs_oracle(lib, arrs, y0, 0.0, 200e3, 201, "munk 200 km")
+    assert ((o["n_bott"] + o["n_surf"]) > 0).sum() > 50 and stats["n"] >= 330
 
 
 def test_fan_vs_oracle_range_dependent_sloping_bottom(lib):
@@ -244,11 +242,7 @@ def test_steps_wider_than_range_cells(lib):
                 np.zeros(len(r))]
         y0 = y0_for(oracle, arrs, 1000.0, 0.0, np.linspace(-18, 18, 130))
         for rtol in (1e-5, 1e-9):
-            # at rtol = 1e-5 the solution itself is only good to ~1e-5: last-bit differences of the
-            # step-size sequence show at the 1e-8 level, so the reference's own test tolerances apply
-            floor = dict(T=1e-6, z=1e-2, p=1e-7) if rtol > 1e-8 else None
-            gpu_vs_oracle(lib, arrs, y0, 0.0, 100e3, 41, f"fine range grid rtol={rtol}", rtol=rtol,
-                          abs_floor=floor)
+            gpu_vs_oracle(lib, arrs, y0, 0.0, 100e3, 41, f"fine range grid rtol={rtol}", rtol=rtol)
 
 
 def test_dropped_rays_and_statuses(lib):
@@ -421,8 +415,8 @@ def test_sample_evaluation_orders_agree(lib):
 # ------------------------------------------------------------------ full size: size-independent properties
 def test_full_size_config1_properties(lib):
     """BASELINE configs[1] at full size (1e5 rays, 1000 km): the oracle cannot run this in
-    seconds, so check properties: (i) a strided 1/500 subset equals the oracle within the
-    parity policy, (ii) determinism, (iii) the range-independent Hamiltonian
+    seconds, so check properties: (i) every 100th ray equals the oracle BIT FOR BIT (at most one
+    ray in a thousand may be an odd one out, helpers.py), (ii) determinism, (iii) the range-independent Hamiltonian
     sqrt(1/c^2 - p^2) is conserved along every ray, (iv) up/down symmetry of step counts is
     not required but bounce counts are monotone in |angle| at the fan edges."""
     arrs = munk_arrays(1000e3)
@@ -441,11 +435,11 @@ def test_full_size_config1_properties(lib):
     assert np.array_equal(a["z"], b["z"], equal_nan=True) and np.array_equal(a["status"], b["status"])
     ok = a["status"] == 0
     assert ok.mean() > 0.999
-    sub = np.arange(0, 100_000, 500)
-    o = oracle.shoot_fan(*arrs, y0[sub], 0.0, 1000e3, 101)
-    noise = oracle_selfnoise(oracle, arrs, y0[sub], 0.0, 1000e3, 101)
+    sub = np.arange(0, 100_000, 100)
+    o = oracle.shoot_fan(*arrs, y0[sub], 0.0, 1000e3, 101, math=oracle.MATH_CR)
     gsub = {k: (v[sub] if isinstance(v, np.ndarray) and v.shape[:1] == (100_000,) else v) for k, v in a.items()}
-    assert_fan_parity(gsub, o, noise_runs=noise, scales=(5000.0, 680.0, 1 / 1500.0), label="config1 subset")
+    st = assert_bit_parity(gsub, o, label="config1, every 100th ray", samples=False)
+    assert st["n"] > 990 and (o["n_bott"] + o["n_surf"] > 0).sum() > 250
     # Hamiltonian at the end state vs at the source
     zc = np.clip(a["end"][ok, 1], 0, 5998.999)
     c_end = np.interp(zc, arrs[3], arrs[0][0])
@@ -460,9 +454,10 @@ def test_full_size_config1_properties(lib):
 
 
 def test_arithmetic_building_blocks(lib):
-    """The kernel's divide / sqrt expansions must be correctly rounded on the operand ranges
-    that occur (they replace the compiler's IEEE expansions), err^-0.2 within 2 ulp, and
-    10*ulp(t) exact."""
+    """The kernel's divide / sqrt expansions must be correctly rounded on the operand ranges that
+    occur (they replace the compiler's IEEE expansions), 10*ulp(t) exact, and the three libm
+    functions of the reference -- err ** -0.2, (0.01/d) ** 0.2, arcsin, sin -- CORRECTLY ROUNDED
+    (csrc/pgr_crmath.h): equal to the oracle's binary128 evaluation rounded once."""
     rng = np.random.default_rng(0)
     M = 1_000_000
     a = rng.uniform(-1e4, 1e4, M) * 10.0 ** rng.integers(-8, 8, M)
@@ -473,30 +468,77 @@ def test_arithmetic_building_blocks(lib):
     assert np.array_equal(o[:, 1], 1 / b)
     assert np.array_equal(o[:, 2], 1 / np.sqrt(b))
     assert np.array_equal(o[:, 3], np.sqrt(b))
-    ref = np.power(b[:300000].astype(np.longdouble), np.longdouble(-0.2)).astype(np.float64)
-    assert (np.abs(o[:300000, 4] - ref) / np.spacing(ref)).max() <= 2.0
     assert np.array_equal(o[:, 5], 10 * np.abs(np.nextafter(a, np.inf) - a))
+    # the correctly rounded functions, on the ranges the integrator feeds them
+    x = np.exp(rng.uniform(np.log(1e-7), np.log(1e4), M))                       # error norms
+    v = np.concatenate([rng.uniform(-1, 1, M // 2), rng.uniform(-1, 1, M // 4) ** 5,
+                        np.sign(rng.uniform(-1, 1, M - M // 2 - M // 4)) * (1 - 10 ** rng.uniform(-16, -0.3, M - M // 2 - M // 4))])
+    o = lib.debug_math(v, x)
+    assert np.array_equal(o[:, 4], oracle.math_fn("pow_m02", x))
+    assert np.array_equal(o[:, 6], oracle.math_fn("pow_p02", x))
+    assert np.array_equal(o[:, 7], oracle.math_fn("asin", v))
+    assert np.array_equal(o[:, 8], oracle.math_fn("sin", v))
+    w = rng.uniform(-6.5, 6.5, M)                                               # radians(theta_b), |theta_b| <= 270 deg
+    assert np.array_equal(lib.debug_math(w, x)[:, 8], oracle.math_fn("sin", w))
+    # (the platform libm is NOT this: glibc differs from the correctly rounded value in ~0.1 % of calls)
+    assert 0 < np.mean(oracle.math_fn("pow_m02", x, math=oracle.MATH_LIBM) != o[:, 4]) < 0.01
+    # The one input class where the kernel's 1/sqrt is off: s = RN(sqrt x) = 1 - 2^-53 (all-ones
+    # significand), i.e. x in {1 - 2^-53, 1 - 2^-52} -- and nothing else near 1
+    k = np.arange(0, 4096.0)
+    near1 = 1.0 - k * 2.0 ** -53
+    got = lib.debug_math(np.ones_like(near1), near1)[:, 2]
+    wrong = np.where(got != 1 / np.sqrt(near1))[0]
+    assert set(wrong.tolist()) <= {1, 2}, wrong
+
+
+def test_step_probe_reproduces_the_oracle_trace(lib):
+    """Every step ATTEMPT of a ray, one at a time: the device's rk_step + error norm + controller
+    power from the oracle's (t, y, h) must give the oracle's y_new, f_new, error_norm and power bit
+    for bit (pgr_debug_step: the tool that found the ERR_HI and 1/sqrt(1 - 2^-53) cases)."""
+    arrs = munk_arrays(300e3)
+    env = lib.EnvHandle(*arrs)
+    y0 = y0_for(oracle, arrs, 1000.0, 0.0, [-17.3, -6.0, 0.4, 11.9])
+    for k in range(len(y0)):
+        tr = oracle.trace_ray(*arrs, y0[k], 0.0, 300e3, math=oracle.MATH_CR)
+        d = env.debug_step(tr[:, 0], tr[:, 2:5], tr[:, 1])
+        assert np.array_equal(d[:, 8:11], tr[:, 5:8])          # f at the start of the attempt
+        assert np.array_equal(d[:, 6], tr[:, 8])               # error norm
+        assert np.array_equal(d[:, 7], 0.9 * oracle.math_fn("pow_m02", tr[:, 8]))
+        nxt = np.arange(1, len(tr))
+        cont = (tr[:-1, 9] == 1) & (tr[nxt, 11] == tr[:-1, 11]) & (tr[nxt, 0] == tr[:-1, 0] + tr[:-1, 1])
+        assert cont.sum() > 100
+        assert np.array_equal(d[:-1][cont, 0:3], tr[nxt][cont, 2:5])   # y_new = the next attempt's y
+        assert np.array_equal(d[:-1][cont, 3:6], tr[nxt][cont, 5:8])   # f_new = its f (FSAL)
+    env.close()
 
 
 def test_exact_bisection_flag_agrees_with_default_locator(lib):
-    """PGR_EXACT_BISECTION runs brentq's ~42-step bisection on the +-1 event; the default
-    locator (Newton on the quartic + verified bracket of brentq's final width) must land on the
-    same roots: identical bounce counts and end states within the parity policy."""
+    """PGR_EXACT_BISECTION runs brentq's ~42-step bisection with the true +-1 event at every
+    iterate; the default locator replays the same iterates and evaluates the event only inside the
+    rounding-noise band around the Newton root.  Both return brentq's root: every output bit equal,
+    and equal to the oracle's (which calls a transcription of brentq itself) -- flat and sloping
+    floors, range dependent tables, the first bounces near x = 0 included."""
     arrs = munk_arrays(300e3)
     y0 = y0_for(oracle, arrs, 1000.0, 0.0, np.linspace(15.0, 20.0, 128))
-    env = lib.EnvHandle(*arrs)
-    a = env.shoot_fan(y0, 0.0, 300e3, 31)
-    b = env.shoot_fan(y0, 0.0, 300e3, 31, exact_bisection=True)
-    o = oracle.shoot_fan(*arrs, y0, 0.0, 300e3, 31)
-    assert (o["n_bott"] + o["n_surf"]).min() >= 5
-    for g in (a, b):
-        assert np.array_equal(g["n_bott"], o["n_bott"]) and np.array_equal(g["n_surf"], o["n_surf"])
-    noise = oracle_selfnoise(oracle, arrs, y0, 0.0, 300e3, 31)
-    assert_fan_parity(a, o, noise_runs=noise, scales=(5000.0, 205.0, 1 / 1500.0), label="default locator")
-    assert_fan_parity(b, o, noise_runs=noise, scales=(5000.0, 205.0, 1 / 1500.0), label="exact bisection")
-    # the two locators agree with each other far better than either needs to with the oracle
-    d = np.abs(a["end"][:, 1] - b["end"][:, 1])
-    assert np.median(d) < 1e-6
+    z = np.arange(0, 5500, 2.0)
+    r = np.linspace(0, 150e3, 61)
+    cin = np.array([munk(z, 1300 + 2e-3 * ri) for ri in r])
+    br = np.linspace(0, 150e3, 31)
+    depths = 4800 + 300 * np.sin(br / 20e3)
+    arrs2 = [cin, np.gradient(cin, z, axis=1, edge_order=1), r, z, depths, br, np.degrees(np.arctan(np.gradient(depths, br)))]
+    y02 = y0_for(oracle, arrs2, 700.0, 0.0, np.linspace(-18, 18, 130))
+    for ar, yy, x1 in ((arrs, y0, 300e3), (arrs2, y02, 140e3)):
+        env = lib.EnvHandle(*ar)
+        a = env.shoot_fan(yy, 0.0, x1, 31, exact_samples=True)
+        b = env.shoot_fan(yy, 0.0, x1, 31, exact_samples=True, exact_bisection=True)
+        o = oracle.shoot_fan(*ar, yy, 0.0, x1, 31, math=oracle.MATH_CR)
+        assert (o["n_bott"] + o["n_surf"]).max() >= 5
+        for k in ("T", "z", "p", "end"):
+            assert np.array_equal(a[k], b[k], equal_nan=True), k
+        for k in ("status", "n_steps", "n_rej", "n_bott", "n_surf"):
+            assert np.array_equal(a[k], b[k]), k
+        assert_bit_parity(b, o, label="exact bisection vs oracle")
+        env.close()
 
 
 def test_edge_shapes_and_inputs(lib):
