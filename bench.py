@@ -1,25 +1,33 @@
 #!/usr/bin/env python3
-"""Headline benchmark: ray-steps/sec of a 1e5-ray Munk fan to 1000 km (BASELINE.json configs[1]).
+"""Headline benchmark: ray-steps/sec of a 1e5-ray Munk fan to 1000 km (BASELINE.json configs[1]),
+plus the eigenray wall-clock of configs[3].
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path over one fan resident in HBM: per rank, 100 000 rays
-(weak scaling: the global fan has N x 100 000 launch angles linspace(-20, 20), dealt to the
-ranks in a strided fashion), Munk profile z = arange(0, 6000, 1), 100 range columns to
-1000 km, flat bottom 5000 m, source (0 m, 1000 m), rtol 1e-9, 1001 saved samples per ray
-(the trajectories pygenray's RayFan holds).  With N > 1 each step ends with the RCCL
-all-gather of the 40-byte end records (pygenray_amd/distributed.py).
+With N > 1 and no WORLD_SIZE in the environment this process only LAUNCHES the N ranks (one per
+GPU, `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`,
+before anything here touches a GPU) and exits with their status; under an external torchrun it is a
+rank.  A "step" is one pass of the hot path over one fan resident in HBM: per rank, `--rays` rays
+(default 100 000; weak scaling: the global fan has N x rays launch angles linspace(-20, 20), dealt
+to the ranks in a strided fashion), Munk profile z = arange(0, 6000, 1), 100 range columns to
+1000 km, flat bottom 5000 m, source (0 m, 1000 m), rtol 1e-9, 1001 saved samples per ray (the
+trajectories pygenray's RayFan holds; `--no-save`: end state only).  With N > 1 each step ends with
+the RCCL all-gather of the 40-byte end records (pygenray_amd/distributed.py); `--histogram` adds the
+4096-bin arrival-time histogram of configs[4] (HIP kernel + all-reduce of the counts), so that
+`--rays 1000000 --no-save --histogram` is configs[4]'s per-GPU shape.
 
-One JSON line on rank 0: value = accepted RK45 steps of all rays on all ranks / wall time
-(max over ranks, barrier + synchronize on both sides).  `roofline` prices the fan kernel
-against HBM with SURVEY.md 8(d)'s algorithmic bytes; `cpu_baseline` times the CPU oracle
-(a port of the reference's integrator -- the reference itself cannot travel to the GPU box)
-on a bounded sample of the same workload, rank 0 at N = 1 only.
+One JSON line on rank 0: value = accepted RK45 steps of all rays on all ranks / wall time (max over
+ranks, barrier + synchronize on both sides).  `roofline` prices the fan kernel against HBM with
+SURVEY.md 8(d)'s algorithmic bytes, `roofline_valu` against the fp64 VALU issue rate that really
+bounds it; `cpu_baseline` is the reference's own call pattern (scipy.integrate.solve_ivp, RK45,
+4 terminal events, NumPy right-hand side: oracle/scipy_port.py -- the reference itself cannot
+travel to the GPU box) on all usable host cores, `cpu_baseline_c` the C/OpenMP oracle; `eigenray`
+the wall-clock of configs[3] (1e6-angle fan + regula-falsi refinement); rank 0 at N = 1 only.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -32,7 +40,46 @@ RAYS_PER_GPU = 100_000
 RANGE_M = 1000e3
 S_SAVE = 1001
 SOURCE_DEPTH = 1000.0
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+SIMDS = 256 * 4            # 256 CUs x 4 SIMDs
+CLOCK_HZ = 2.4e9           # max shader clock (MI355X_MICROARCH.md)
+FP64_CYCLES_PER_WAVE_INSTR = 4  # 16 fp64 lanes per clock per SIMD: a wave64 instruction holds the pipe 4 cycles
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rays", type=int, default=RAYS_PER_GPU, help="rays per GPU")
+    ap.add_argument("--layout", choices=["ray", "sample"], default="sample",
+                    help="trajectory layout in HBM: [S][N] (default: coalesced stores; the drop-in API\n"
+                         "hands RayFan a transposed (N,S) view of it) or [N][S] (4.4x HBM write amplification)")
+    ap.add_argument("--no-save", action="store_true", help="end state only (B_alg = 80 B)")
+    ap.add_argument("--histogram", action="store_true",
+                    help="each step also bins the arrival times (4096 bins) on the device and all-reduces the counts")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-eigenray", action="store_true")
+    ap.add_argument("--eigen-rays", type=int, default=1_000_000, help="fan size of the eigenray leg (configs[3])")
+    ap.add_argument("--waves-per-block", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; tests rehearse with gloo)")
+    ap.add_argument("--launcher-only", action="store_true", help="(tests) start the ranks, let them report, do no GPU work")
+    return ap.parse_args(argv)
+
+
+def spawn_ranks(args, argv):
+    """`bench.py --gpus N` run plainly: start N ranks of this script (one process per GPU) and return
+    their exit status.  Nothing in this (parent) process has initialised a GPU; the ranks are fresh
+    children, rank 0 prints the JSON line, and a rank that fails to join fails the whole run."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
 
 
 def munk_tables(r_max, nr=100):
@@ -59,7 +106,7 @@ def host_cores():
     return n
 
 
-def cpu_baseline(arrs, n_rays=25000):
+def cpu_baseline_c(arrs, n_rays=25000):
     """CPU oracle (C port of the reference integrator, OpenMP over rays, one thread per usable
     core) on a bounded sample: every (100000/n_rays)-th ray of the same fan, full 1000 km,
     trajectories included (about 30 core-seconds)."""
@@ -77,58 +124,128 @@ def cpu_baseline(arrs, n_rays=25000):
     return {"value": steps / dt, "unit": "ray-steps/s", "cores": cores,
             "kind": "port",
             "sample": f"{len(y0)} rays (every {RAYS_PER_GPU // n_rays}th of the 1e5-ray fan), "
-                      f"1000 km, {steps} ray-steps in {dt:.1f} s, oracle/ray_oracle.c with OpenMP, "
+                      f"1000 km, {steps} ray-steps in {dt:.1f} s, oracle/ray_oracle.c (libm mode) with OpenMP, "
                       f"{cores} threads (cgroup CPU quota of the box)"}
 
 
-def scipy_baseline(arrs, n_rays=12):
-    """The NumPy/SciPy call pattern of the reference (solve_ivp RK45 + events), one core."""
+def _scipy_chunk(job):
+    """One pool task: a chunk of rays through the reference's solve_ivp call pattern."""
+    arrs, y0 = job
     from oracle import scipy_port
-    from pygenray_amd.device_fan import fan_y0
-    theta = np.linspace(-20, 20, RAYS_PER_GPU)[:: RAYS_PER_GPU // n_rays][:n_rays]
-    y0 = fan_y0(arrs, SOURCE_DEPTH, 0.0, -theta)
-    t0 = time.time()
     out = scipy_port.shoot_fan(*arrs, y0, 0.0, RANGE_M, S_SAVE)
-    dt = time.time() - t0
-    steps = int(out["n_steps"].sum())
-    return {"value": steps / dt, "unit": "ray-steps/s", "cores": 1, "kind": "port",
-            "sample": f"{len(y0)} rays, 1000 km, {steps} ray-steps in {dt:.1f} s, "
-                      f"oracle/scipy_port.py (scipy.integrate.solve_ivp, un-jitted RHS)"}
+    return int(out["n_steps"].sum()), int((out["status"] == 0).sum())
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rays", type=int, default=RAYS_PER_GPU, help="rays per GPU")
-    ap.add_argument("--layout", choices=["ray", "sample"], default="sample",
-                    help="trajectory layout in HBM: [S][N] (default: coalesced stores; the drop-in API\n"
-                         "hands RayFan a transposed (N,S) view of it) or [N][S] (4.4x HBM write amplification)")
-    ap.add_argument("--no-save", action="store_true", help="end state only (B_alg = 80 B)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--waves-per-block", type=int, default=0)
-    args = ap.parse_args()
+def cpu_baseline_scipy(arrs, seconds_budget=25.0):
+    """the NumPy/SciPy call pattern of the reference -- solve_ivp(RK45, rtol 1e-9, atol
+    1e-6, dense output, 4 terminal events, REF/launch_rays.py:670-679) restarted at every bounce, NumPy
+    right-hand side (un-jitted: the reference's numba decorator is not available here either) -- on ALL
+    usable host cores through a spawn pool, one chunk of rays per task (the reference's pool maps one
+    ray per task, REF/launch_rays.py:157-164), on a strided subset of the same 1e5-ray fan sized to the
+    time budget."""
+    import multiprocessing as mp
+    from pygenray_amd.device_fan import fan_y0
+    cores = host_cores()
+    # ~0.12 s per 1000-km ray and core (11 k ray-steps/s): size the sample to ~seconds_budget of wall clock
+    n_rays = int(max(cores * 4, min(4000, cores * seconds_budget / 0.14)))
+    stride = max(1, RAYS_PER_GPU // n_rays)
+    theta = np.linspace(-20, 20, RAYS_PER_GPU)[::stride][:n_rays]
+    y0 = fan_y0(arrs, SOURCE_DEPTH, 0.0, -theta)
+    order = np.random.default_rng(0).permutation(len(y0))   # mix steep and shallow rays over the tasks
+    chunks = [(arrs, y0[order[k::cores * 4]]) for k in range(cores * 4)]
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(cores) as pool:
+        pool.map(_noop, range(cores))          # workers up, imports done, before the clock starts
+        t0 = time.time()
+        res = pool.map(_scipy_chunk, chunks, chunksize=1)
+        dt = time.time() - t0
+    steps = sum(r[0] for r in res)
+    return {"value": steps / dt, "unit": "ray-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{len(y0)} rays (every {stride}th of the 1e5-ray fan), 1000 km, {steps} ray-steps in {dt:.1f} s: "
+                      f"oracle/scipy_port.py = scipy.integrate.solve_ivp(RK45, 4 terminal events, dense output) with a "
+                      f"NumPy right-hand side (pygenray's call pattern, un-jitted), spawn pool of {cores} processes"}
 
-    import torch
-    import torch.distributed as dist
-    from pygenray_amd import _lib
-    from pygenray_amd.device_fan import DeviceFan, fan_y0
-    from pygenray_amd.distributed import shard_indices, all_gather_fan, start_all_gather_records
+
+def _noop(_):
+    import oracle.scipy_port  # noqa: F401
+    return 0
+
+
+def eigenray_leg(env_obj, n_rays):
+    """BASELINE configs[3]: fixed source / receiver, a fan of n_rays launch angles (end state only)
+    then pygenray's regula falsi on every bracket (REF/eigenrays.py:62-203), receiver depth 1000 m,
+    ztol 1 m, max_iter 20: wall clock through the drop-in API, second run (tables resident)."""
+    import pygenray_amd as pr
+    from pygenray_amd import eigenrays as er_mod
+    angles = np.linspace(-20, 20, n_rays)
+    out = None
+    for _ in range(2):
+        er_mod.LAST_SEARCH_STATS.clear()
+        t0 = time.perf_counter()
+        fan = pr.shoot_rays(SOURCE_DEPTH, 0.0, angles, RANGE_M, 2, env_obj, debug=False, flatearth=False)
+        t1 = time.perf_counter()
+        er = pr.find_eigenrays(fan, [1000.0], SOURCE_DEPTH, 0.0, RANGE_M, 2, env_obj, ztol=1, max_iter=20,
+                               debug=False, flatearth=False, quiet=True)
+        t2 = time.perf_counter()
+        out = {"wall_s": t2 - t0, "fan_s": t1 - t0, "search_s": t2 - t1, "fan_rays": n_rays,
+               "brackets": int(er.num_eigenrays[1000.0]), "found": int(er.num_eigenrays_found[0]),
+               "failed": len(er.failed_eray_theta_brackets[0]),
+               "launches": int(er_mod.LAST_SEARCH_STATS.get("launches", 0)),
+               "config": "configs[3]: Munk dz=1 m, source (0, 1000 m), receiver (1000 km, 1000 m), "
+                         "ztol 1 m, max_iter 20; through pr.shoot_rays + pr.find_eigenrays, host buffers included"}
+    return out
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args, argv))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if rank == 0 and world > 1:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+        # launched under an external torchrun with a different rank count: the JSON line must not lie
+        if rank == 0:
+            print(f"error: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+        sys.exit(2)
+
+    import torch
+    import torch.distributed as dist
+    if args.launcher_only:
+        # (CPU rehearsal of the launcher, tests/test_host.py: every rank joins, rank 0 reports)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(args.backend)
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"launcher_only": True, "n_gpus": world, "ranks_joined": int(t.item())}))
+        dist.barrier()
+        dist.destroy_process_group()
+        sys.exit(0 if int(t.item()) == args.gpus else 3)
+
+    from pygenray_amd import _lib
+    from pygenray_amd.device_fan import DeviceFan, fan_y0
+    from pygenray_amd.distributed import shard_indices, start_all_gather_records, arrival_time_histogram
+
     torch.cuda.set_device(local_rank)
     # PGR_BENCH_FORCE_DIST=1 rehearses the N > 1 code path (RCCL init, all-gather, reductions)
     # with a single rank on a one-GPU box
     use_dist = world > 1 or os.environ.get("PGR_BENCH_FORCE_DIST") == "1"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if "RANK" not in os.environ:   # the one-rank rehearsal outside a launcher
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        dist.init_process_group(args.backend, device_id=torch.device("cuda", local_rank))
+        joined = torch.ones(1, device="cuda")
+        dist.all_reduce(joined)
+        if int(joined.item()) != world:
+            sys.exit(3)
 
     _lib.load()
     if args.waves_per_block:
@@ -143,11 +260,22 @@ def main():
     # N > 1: the kernel writes the 40-byte end records of the all-gather itself (PGR_PACKED_END)
     fan = DeviceFan(env, y0, 0.0, RANGE_M, S_SAVE, save=save, sample_major=(args.layout == "sample"),
                     packed_end=use_dist, n_pad=(n_global + world - 1) // world)
+    HIST_BINS, T_LO, T_HI = 4096, RANGE_M / 1560.0, RANGE_M / 1480.0
+    hist = None
 
-    def step():
-        fan.run()
+    def step_collectives(pending):
+        """what follows a fan pass: the histogram of configs[4] and the all-gather of the end records"""
+        nonlocal hist
+        if args.histogram:
+            t_end = fan.records[:fan.N, 0] if use_dist else fan.end[:, 0]
+            hist = arrival_time_histogram(t_end, fan.status, HIST_BINS, T_LO, T_HI, reduce=use_dist)
         if use_dist:
-            return start_all_gather_records(fan.records, n_global).finish()
+            # the end records of pass k travel (RCCL stream) while pass k+1 integrates; every
+            # gathered fan is reassembled in launch-angle order before the clock stops
+            started = start_all_gather_records(fan.records, n_global)
+            if pending is not None:
+                pending.finish()
+            return started
         return None
 
     def fence():
@@ -156,8 +284,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    pending = None
     for _ in range(args.warmup):
-        step()
+        fan.run()
+        pending = step_collectives(pending)
+    if pending is not None:
+        pending.finish()
     fence()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
@@ -167,13 +299,7 @@ def main():
         ev[k][0].record()
         fan.run()
         ev[k][1].record()
-        if use_dist:
-            # the end records of pass k travel (RCCL stream) while pass k+1 integrates; every
-            # gathered fan is reassembled in launch-angle order before the clock stops
-            started = start_all_gather_records(fan.records, n_global)
-            if pending is not None:
-                pending.finish()
-            pending = started
+        pending = step_collectives(pending)
     if pending is not None:
         pending.finish()
     fence()
@@ -197,10 +323,12 @@ def main():
         mean_steps = local_steps / max(fan.N - int((fan.status != 0).sum().item()), 1)
         b_alg = 80.0 + (24.0 * S_SAVE / mean_steps if save else 0.0)
         achieved = local_steps * b_alg / (kern_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
-        # (profiles/r01_traffic.json: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE)
-        traffic = traffic_gb = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        # HBM bytes and VALU wave-instructions per launch from the committed rocprofv3 PMC passes of this
+        # same command (profiles/r02_traffic.json: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE;
+        # SQ_INSTS_VALU), used only when they were taken at this ray count
+        traffic = traffic_gb = valu = None
+        tnote = "no committed PMC pass for this configuration"
+        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
@@ -208,32 +336,48 @@ def main():
                 if key in tj and tj[key].get("rays") == fan.N:
                     traffic_gb = tj[key]["hbm_gb_per_launch"]
                     traffic = traffic_gb / (kern_ms * 1e-3)
+                    valu = tj[key].get("valu_wave_instructions_per_launch")
+                    tnote = tj[key].get("note", "profiles/r02_traffic.json")
             except Exception:
                 traffic = None
         out = {
-            "metric": "ray-steps/sec (whole node), 1e5-ray Munk fan to 1000 km",
+            "metric": "ray-steps/sec (whole node), 1e5-ray Munk fan to 1000 km; eigenray wall-clock",
             "value": value, "unit": "ray-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "configs[1]: Munk SSP dz=1 m, 100000 launch angles per GPU "
-                                   "linspace(-20,20), 1000 km, rtol 1e-9, fp64",
+            "config": {"workload": f"configs[1]: Munk SSP dz=1 m, {fan.N} launch angles per GPU "
+                                   "linspace(-20,20), 1000 km, rtol 1e-9, fp64"
+                                   + (", + 4096-bin arrival-time histogram (configs[4] shape)" if args.histogram else ""),
                        "rays_per_gpu": fan.N, "num_range_save": S_SAVE if save else 0,
                        "trajectory_layout": args.layout if save else "none",
                        "ray_steps_per_pass": total_steps, "dropped_rays": n_drop,
+                       "histogram_bins": HIST_BINS if args.histogram else 0,
                        "sharding": "strided launch angles, all-gather of end records" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_gb_per_launch": traffic_gb,
+                         "traffic_gb_per_launch": traffic_gb, "traffic_source": tnote,
                          "algorithmic_gb_per_launch": local_steps * b_alg / 1e9,
                          "kernel": f"pgr_fan_kernel<true, 4, {1 if save else 0}> (table in LDS, zin = j * 1 m, "
                                    f"{'linspace save grid' if save else 'end state only'})", "kernel_ms": kern_ms,
                          "bytes_per_ray_step": b_alg,
                          "note": "algorithmic bytes per SURVEY 8(d); the stepper keeps state in "
                                  "VGPRs and the SSP table in LDS, so it is fp64-VALU bound, not HBM bound"},
+            "build": _lib.build_info(),
         }
+        if valu:
+            slots = SIMDS * CLOCK_HZ / FP64_CYCLES_PER_WAVE_INSTR * kern_ms * 1e-3
+            out["roofline_valu"] = {"bound": "fp64 VALU issue", "achieved": valu, "peak": slots,
+                                    "unit": "wave-instructions per launch", "frac": valu / slots,
+                                    "note": "SQ_INSTS_VALU of the fan kernel (committed PMC pass) over 1024 SIMDs x 2.4 GHz / 4 "
+                                            "cycles x this run's kernel time: the bound that really holds (every VALU "
+                                            "instruction of the stepper is fp64 or issues at the same 4-cycle cadence)"}
+        if args.histogram and hist is not None:
+            out["histogram"] = {"bins": HIST_BINS, "range_s": [T_LO, T_HI], "counted_rays": int(hist.sum().item())}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(arrs)
-            out["cpu_baseline_scipy"] = scipy_baseline(arrs)
+            out["cpu_baseline"] = cpu_baseline_scipy(arrs)
+            out["cpu_baseline_c"] = cpu_baseline_c(arrs)
+        if world == 1 and not args.no_eigenray:
+            out["eigenray"] = eigenray_leg(env_obj, args.eigen_rays)
         print(json.dumps(out))
     if use_dist:
         dist.barrier()

@@ -173,6 +173,11 @@ int pgr_debug_math(const double* a, const double* b, int64_t M, double* out9);
 int pgr_debug_step(pgr_env* env, const double* t, const double* y, const double* h, int64_t M,
                    double rtol, double atol, double* out11);
 
+/* What this build of the library is: whether the instruction-layout pass of the build was applied
+ * ("relaid: 502 -> 31 straddles ..." or "plain hipcc") and which arithmetic variant was compiled.
+ * bench.py puts it into its JSON line so that a measured number names the binary it came from. */
+const char* pgr_build_info(void);
+
 /* Message for the last error on the calling thread. */
 const char* pgr_last_error(void);
 

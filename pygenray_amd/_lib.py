@@ -99,6 +99,15 @@ def _relayout(td, verbose):
         raise RuntimeError("unexpected layout of the fat binary in the host assembly")
     h = (h[:i] + b'\t.incbin\t"' + fb.encode() + b'"\n\t.size\t' + m.group(1) + b", " +
          str(os.path.getsize(fb)).encode() + h[k:])
+    # ... and say so in the library: pgr_build_info() reads this tag (same length, so nothing moves)
+    b = sum(v[0] for v in report.values()); a = sum(v[1] for v in report.values())
+    tag0 = b"PGR_BUILD_TAG:plain hipcc"
+    k0 = h.index(tag0)
+    k1 = h.index(b'"', k0)
+    tag = (f"PGR_BUILD_TAG:relaid, {b} -> {a} straddling 8-byte instructions").encode()
+    if len(tag) > k1 - k0:
+        raise RuntimeError("build tag too long")
+    h = h[:k0] + tag + b" " * (k1 - k0 - len(tag)) + h[k1:]
     host2_s, host2_o = os.path.join(td, "host2.s"), os.path.join(td, "host2.o")
     with open(host2_s, "wb") as f:
         f.write(h)
@@ -106,7 +115,6 @@ def _relayout(td, verbose):
     out = os.path.join(td, "relaid.so")
     run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, host2_o])
     if verbose:
-        b = sum(v[0] for v in report.values()); a = sum(v[1] for v in report.values())
         print(f"instruction layout: {b} -> {a} 8-byte instructions straddle a 32-byte fetch window "
               f"({sum(v[2] for v in report.values())} re-encoded as e64)")
     return out
@@ -339,6 +347,13 @@ def debug_math(a, b):
 
 def device_count():
     return load().pgr_device_count()
+
+
+def build_info():
+    """pgr_build_info(): layout pass applied or not + arithmetic variant of the loaded library."""
+    L = load()
+    L.pgr_build_info.restype = ctypes.c_char_p
+    return L.pgr_build_info().decode()
 
 
 def arrival_histogram_device(device, t_ptr, t_stride, status_ptr, status_stride, n, t_min, t_max, nbins,

@@ -1802,6 +1802,44 @@ struct pgr_env {
 
 extern "C" const char* pgr_last_error(void) { return g_err.c_str(); }
 
+// What the build did to this library: the second pass of the build (pygenray_amd/_isa_layout.py, run
+// by pygenray_amd/_lib.py) re-encodes the device code and, when it has succeeded, overwrites this tag
+// in the host object -- "plain hipcc" means the pass did not run or failed and the unmodified hipcc
+// output is what is loaded.  The arithmetic switches come from the preprocessor.
+extern "C" {
+__attribute__((used)) char pgr_build_tag[96] = "PGR_BUILD_TAG:plain hipcc                                                                     ";
+}
+extern "C" const char* pgr_build_info(void)
+{
+    static std::string info;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        std::string t(pgr_build_tag + 14);
+        while (!t.empty() && t.back() == ' ') t.pop_back();
+        info = "layout: " + t + "; arithmetic: ";
+#if defined(PGR_FMA)
+        info += "FMA contraction (experiments only)";
+#elif defined(PGR_STRICT)
+        info += "compiler IEEE divide/sqrt";
+#else
+        info += "reference order, correctly rounded div/sqrt/pow/asin/sin";
+#endif
+#ifdef PGR_EXACT_RSQRT
+        info += ", exact 1/sqrt";
+#endif
+#ifdef PGR_POW_2ULP
+        info += ", 2-ulp pow (NOT bit-identical)";
+#endif
+#ifdef PGR_NO_REPLAY
+        info += ", no brentq replay (NOT bit-identical)";
+#endif
+#ifdef PGR_LIBM_TRIG
+        info += ", device-library asin/sin (NOT bit-identical)";
+#endif
+    });
+    return info.c_str();
+}
+
 extern "C" int pgr_device_count(void)
 {
     int n = 0;

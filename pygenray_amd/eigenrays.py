@@ -12,6 +12,9 @@ import numpy as np
 from .launch_rays import _shoot_ode_angles
 from .ray_objects import RayFan, EigenRays
 
+# diagnostics of the last find_eigenrays call (bench.py reports them): fan launches and trial rays
+LAST_SEARCH_STATS = {}
+
 
 def _regula_falsi_batch(z1, z2, th1, th2, receiver_depth, source_depth, source_range,
                         receiver_range, num_range_save, environment, ztol, max_iter, kwargs):
@@ -21,6 +24,7 @@ def _regula_falsi_batch(z1, z2, th1, th2, receiver_depth, source_depth, source_r
     terminate_backwards = kwargs.get("terminate_backwards", True)
     flatearth = kwargs.get("flatearth", True)
     device = kwargs.get("device", 0)
+    quiet = kwargs.get("quiet", False)   # (not a reference kwarg: suppresses the per-bracket failure message)
     nbk = len(z1)
     z1, z2, th1, th2 = (np.array(a, dtype=float) for a in (z1, z2, th1, th2))
     theta = th1 - (z1 + receiver_depth) * (th2 - th1) / (z2 - z1)  # REF/eigenrays.py:118-120
@@ -37,10 +41,12 @@ def _regula_falsi_batch(z1, z2, th1, th2, receiver_depth, source_depth, source_r
         # shoot_ray(theta): ODE angle = -theta (REF/launch_rays.py:251)
         out = _shoot_ode_angles(source_depth, source_range, -theta[idx], receiver_range, S,
                                 environment, rtol, terminate_backwards, flatearth, device=device)
+        LAST_SEARCH_STATS["launches"] = LAST_SEARCH_STATS.get("launches", 0) + 1
+        LAST_SEARCH_STATS["trial_rays"] = LAST_SEARCH_STATS.get("trial_rays", 0) + len(idx)
         r = out["r"]
         dropped = out["status"] != 0
         zend = -out["z"][:, -1]  # stored convention ray.z[-1]
-        for q in idx[dropped]:
+        for q in ([] if quiet else idx[dropped]):
             # REF/eigenrays.py:241-245
             print(f"Failed to find eigen ray for receiver depth {receiver_depth} [m] and "
                   f"approximate launch angle {theta[q]} [m] ray θ = 90°")
