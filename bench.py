@@ -248,10 +248,10 @@ def main(argv=None):
             sys.exit(3)
 
     _lib.load()
-    if args.waves_per_block:
-        _lib.set_waves_per_block(args.waves_per_block)
     env_obj, arrs = munk_tables(RANGE_M)
     env = _lib.EnvHandle(*arrs, device=local_rank)
+    if args.waves_per_block:
+        env.set_option("waves_per_block", args.waves_per_block)
     n_global = args.rays * world
     theta = np.linspace(-20, 20, n_global)
     idx = shard_indices(n_global, rank, world)
@@ -260,7 +260,7 @@ def main(argv=None):
     # N > 1: the kernel writes the 40-byte end records of the all-gather itself (PGR_PACKED_END)
     fan = DeviceFan(env, y0, 0.0, RANGE_M, S_SAVE, save=save, sample_major=(args.layout == "sample"),
                     packed_end=use_dist, n_pad=(n_global + world - 1) // world)
-    HIST_BINS, T_LO, T_HI = 4096, RANGE_M / 1560.0, RANGE_M / 1480.0
+    HIST_BINS, T_LO, T_HI = 4096, RANGE_M / 1560.0, RANGE_M / 1400.0
     hist = None
 
     def step_collectives(pending):

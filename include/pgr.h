@@ -108,7 +108,8 @@ int pgr_env_query(const pgr_env* env, int what);
  *   n_bott,n_surf [N] bounce counts ; status [N] ; n_steps [N] accepted RK45 steps ;
  *   n_rej [N] rejected attempts (n_steps/n_rej may be NULL)
  *
- * pgr_shoot_fan takes HOST pointers (copies in/out, synchronous).
+ * pgr_shoot_fan takes HOST pointers (copies in/out, synchronous): everything it does is enqueued on a
+ * stream owned by `env` and it waits for that stream only; calls on one env are serialised.
  * pgr_shoot_fan_device takes DEVICE pointers on env's device, enqueues on `stream`
  * (hipStream_t as void*, NULL = default stream) and returns without synchronising. */
 int pgr_shoot_fan(pgr_env* env, const double* y0, int64_t N, double source_range,
@@ -136,23 +137,25 @@ int pgr_arrival_histogram_device(int device, const double* t_end, int64_t t_stri
                                  double t_min, double t_max, int32_t nbins, int64_t* counts,
                                  void* stream);
 
-/* Depth-cell search for a non-uniform zin (never changes results): 0 (default) = from LDS: the cell
- * of z is j0 or j0 + 1 with j0 = floor(g(z) - 0.5) from a quadratic index estimate g when zin is
- * smooth enough (the flat-earth grid is), else j0 = bucket[floor((z - z0)/w)] from a bin table;
- * 1 = always the binary search of np.searchsorted (REF/integration_processes.py:152-157);
- * 2 = the bin table even when the quadratic would do.  Tests compare the three. */
-int pgr_set_depth_search(int mode);
-
-/* Tuning knobs (process-wide; per-ray results do not depend on them):
- * waves (of 64 rays) per workgroup, 0 = automatic; and the bounce-service batching: a wave
- * services its parked (bounced) lanes when `lanes` of them wait or the oldest waited `trips`
- * step attempts. */
-int pgr_set_waves_per_block(int waves);
-int pgr_set_park(int lanes, int trips);
-/* Cost-aware wave scheduling for fans of 1-2 waves per SIMD: 2 (default) = the costliest
- * waves get a SIMD to themselves / are paired with the cheapest, plus issue priorities by cost
- * quartile; 1 = priorities only on the strided deal; 0 = strided deal. */
-int pgr_set_placement(int mode);
+/* Tuning options of ONE environment (per-ray results never depend on them; there is no process-wide
+ * state: host threads that drive different GPUs hold different environments).
+ *   PGR_OPT_WAVES_PER_BLOCK  a = waves (of 64 rays) per workgroup, 0 = automatic
+ *   PGR_OPT_DEPTH_SEARCH     depth-cell search for a non-uniform zin: a = 0 (default) from LDS -- the cell
+ *                            of z is j0 or j0 + 1 with j0 = floor(g(z) - 0.5) from a quadratic index
+ *                            estimate g when zin is smooth enough (the flat-earth grid is), else j0 =
+ *                            bucket[floor((z - z0)/w)] from a bin table; a = 1 always the binary search of
+ *                            np.searchsorted (REF/integration_processes.py:152-157); a = 2 the bin table
+ *                            even when the quadratic would do.  Tests compare the three.
+ *   PGR_OPT_PARK             bounce-service batching: a wave services its parked (bounced) lanes when `a`
+ *                            of them wait or the oldest waited `b` step attempts (default 64, 16)
+ *   PGR_OPT_PLACEMENT        cost-aware wave scheduling for fans of 1-2 waves per SIMD: a = 2 (default) the
+ *                            costliest waves get a SIMD to themselves / are paired with the cheapest, plus
+ *                            issue priorities by cost quartile; 1 = priorities only; 0 = strided deal */
+#define PGR_OPT_WAVES_PER_BLOCK 0
+#define PGR_OPT_DEPTH_SEARCH 1
+#define PGR_OPT_PARK 2
+#define PGR_OPT_PLACEMENT 3
+int pgr_env_set_option(pgr_env* env, int what, int a, int b);
 
 /* Unit-level device entry points (for parity tests of a1-a8, REF/integration_processes.py):
  * evaluate on the GPU, for M query points (x[k], y[k][3]) given as HOST arrays:

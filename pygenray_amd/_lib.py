@@ -203,12 +203,8 @@ def load():
     L.pgr_shoot_fan.argtypes = fan_common
     L.pgr_shoot_fan_device.restype = ctypes.c_int
     L.pgr_shoot_fan_device.argtypes = fan_common + [_vp]
-    L.pgr_set_depth_search.restype = ctypes.c_int
-    L.pgr_set_depth_search.argtypes = [ctypes.c_int]
-    L.pgr_set_waves_per_block.restype = ctypes.c_int
-    L.pgr_set_waves_per_block.argtypes = [ctypes.c_int]
-    L.pgr_set_park.restype = ctypes.c_int
-    L.pgr_set_park.argtypes = [ctypes.c_int, ctypes.c_int]
+    L.pgr_env_set_option.restype = ctypes.c_int
+    L.pgr_env_set_option.argtypes = [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     L.pgr_eval_points.restype = ctypes.c_int
     L.pgr_eval_points.argtypes = [_vp, _dp, _dp, _i64, _dp]
     _lib = L
@@ -254,6 +250,12 @@ class EnvHandle:
     def query(self, what):
         return load().pgr_env_query(self._h, int(what))
 
+    # tuning options of this environment (include/pgr.h; results never depend on them)
+    _OPTIONS = {"waves_per_block": 0, "depth_search": 1, "park": 2, "placement": 3}
+
+    def set_option(self, name, a, b=0):
+        check(load().pgr_env_set_option(self._h, self._OPTIONS[name], int(a), int(b)))
+
     @property
     def range_independent(self):
         return bool(self.query(0))
@@ -276,7 +278,9 @@ class EnvHandle:
     # ---- host-pointer entry (NumPy in / NumPy out) ----
     def shoot_fan(self, y0, source_range, receiver_range, num_range_save, rtol=1e-9, atol=1e-6,
                   terminate_backwards=True, max_steps=1_000_000, save=True, sample_major=False,
-                  exact_bisection=False, exact_samples=False, stored_sign=False, compact=False):
+                  exact_bisection=False, exact_samples=False, stored_sign=False, compact=False, buffers=None):
+        """``buffers``: (T, Z, P) float64 arrays of the right shape to write into (caller-owned, e.g.
+        reused across fans) instead of fresh ones."""
         L = load()
         y0 = _c(y0).reshape(-1, 3)
         N, S = len(y0), int(num_range_save)
@@ -287,7 +291,13 @@ class EnvHandle:
             (PGR_COMPACT if (compact and sample_major) else 0)
         if save:
             shape = (S, N) if sample_major else (N, S)
-            T = np.empty(shape); Z = np.empty(shape); P = np.empty(shape)
+            if buffers is not None:
+                T, Z, P = buffers
+                for b_ in (T, Z, P):
+                    if b_.shape != shape or b_.dtype != np.float64 or not b_.flags.c_contiguous:
+                        raise ValueError(f"buffers must be C-contiguous float64 arrays of shape {shape}")
+            else:
+                T = np.empty(shape); Z = np.empty(shape); P = np.empty(shape)
         else:
             T = Z = P = None
         end = np.empty((N, 3))
@@ -366,21 +376,3 @@ def arrival_histogram_device(device, t_ptr, t_stride, status_ptr, status_stride,
     check(L.pgr_arrival_histogram_device(int(device), _vp(t_ptr), int(t_stride), _vp(status_ptr or None),
                                          int(status_stride), int(n), float(t_min), float(t_max), int(nbins),
                                          _vp(counts_ptr), _vp(stream or None)))
-
-
-def set_depth_search(mode):
-    """0: automatic (index polynomial or bucket table in LDS for a non-uniform zin), 1: binary search,
-    2: bucket table only."""
-    check(load().pgr_set_depth_search(int(mode)))
-
-
-def set_waves_per_block(w):
-    check(load().pgr_set_waves_per_block(int(w)))
-
-
-def set_park(lanes, trips):
-    check(load().pgr_set_park(int(lanes), int(trips)))
-
-
-def set_placement(mode):
-    check(load().pgr_set_placement(int(mode)))

@@ -1761,10 +1761,6 @@ __global__ void pgr_math_kernel(const double* a, const double* b, int64_t M, dou
 // host side
 // ====================================================================================
 static thread_local std::string g_err;
-static int g_waves_per_block = 0;
-static int g_depth_search = 0;  // 0: automatic, 1: binary search only, 2: bucket table but no index polynomial (tests)
-static int g_park_lanes = 64, g_park_trips = 16;
-static int g_place = 2;  // 0 off, 1 issue priorities only, 2 cost-aware placement + priorities
 
 static int fail(const std::string& m)
 {
@@ -1780,6 +1776,13 @@ static int fail(const std::string& m)
 
 struct pgr_env {
     int device = 0;
+    // tuning options of THIS environment (pgr_env_set_option; per-ray results never depend on them).
+    // No process-wide state: two host threads driving two GPUs keep two environments.
+    int waves_per_block = 0;          // 0 = automatic
+    int depth_search = 0;             // 0: automatic, 1: binary search only, 2: bucket table but no index polynomial (tests)
+    int park_lanes = 64, park_trips = 16;
+    int place = 2;                    // 0 off, 1 issue priorities only, 2 cost-aware placement + priorities
+    hipStream_t stream = nullptr;     // the host-pointer entry's own stream (created on first use)
     EnvDev d{};
     const EnvDev* d_dev = nullptr;  // device copy of `d` (kernel argument by pointer)
     // grow-only staging workspace of the host-pointer entry (kept while <= 256 MB so the many
@@ -1847,33 +1850,30 @@ extern "C" int pgr_device_count(void)
     return n;
 }
 
-extern "C" int pgr_set_park(int lanes, int trips)
+extern "C" int pgr_env_set_option(pgr_env* env, int what, int a, int b)
 {
-    if (lanes < 1 || lanes > 64 || trips < 0 || trips > 100000) return fail("pgr_set_park: lanes in [1,64], trips >= 0");
-    g_park_lanes = lanes;
-    g_park_trips = trips;
-    return 0;
-}
-
-extern "C" int pgr_set_placement(int mode)
-{
-    if (mode < 0 || mode > 2) return fail("pgr_set_placement: 0 = off, 1 = priorities only, 2 = placement + priorities");
-    g_place = mode;
-    return 0;
-}
-
-extern "C" int pgr_set_depth_search(int mode)
-{
-    if (mode < 0 || mode > 2) return fail("pgr_set_depth_search: 0 = automatic, 1 = binary search, 2 = bucket table (no index polynomial)");
-    g_depth_search = mode;
-    return 0;
-}
-
-extern "C" int pgr_set_waves_per_block(int waves)
-{
-    if (waves < 0 || waves > 8) return fail("waves per block must be in [0,8]");
-    g_waves_per_block = waves;
-    return 0;
+    if (!env) return fail("pgr_env_set_option: null env");
+    switch (what) {
+    case PGR_OPT_WAVES_PER_BLOCK:
+        if (a < 0 || a > 8) return fail("waves per block must be in [0,8]");
+        env->waves_per_block = a;
+        return 0;
+    case PGR_OPT_DEPTH_SEARCH:
+        if (a < 0 || a > 2) return fail("depth search: 0 = automatic, 1 = binary search, 2 = bucket table (no index polynomial)");
+        env->depth_search = a;
+        return 0;
+    case PGR_OPT_PARK:
+        if (a < 1 || a > 64 || b < 0 || b > 100000) return fail("park: lanes in [1,64], trips >= 0");
+        env->park_lanes = a;
+        env->park_trips = b;
+        return 0;
+    case PGR_OPT_PLACEMENT:
+        if (a < 0 || a > 2) return fail("placement: 0 = off, 1 = priorities only, 2 = placement + priorities");
+        env->place = a;
+        return 0;
+    default:
+        return fail("pgr_env_set_option: unknown option");
+    }
 }
 
 // grid[j] == g0 + j*dg for all j, evaluated exactly as the device does (mul, then add)
@@ -1948,6 +1948,7 @@ extern "C" void pgr_env_destroy(pgr_env* env)
     (void)hipSetDevice(env->device);
     for (void* p : env->allocs) (void)hipFree(p);
     if (env->ws) (void)hipFree(env->ws);
+    if (env->stream) (void)hipStreamDestroy(env->stream);
     delete env;
 }
 
@@ -2117,11 +2118,11 @@ static int schedule_waves(pgr_env* env, const double* y0, int64_t N, int64_t wav
                           const int*& map_out, int64_t& blocks)
 {
     map_out = nullptr;
-    if (g_place == 0 || g_waves_per_block != 0 || W < 5 || waves > (1 << 27)) return 0;
+    if (env->place == 0 || env->waves_per_block != 0 || W < 5 || waves > (1 << 27)) return 0;
     const int64_t cus = env->num_cus;
     int mode, B;
     if (waves <= 8 * cus && W <= 8 && waves > 4 * cus) {  // single round, 1-2 waves per SIMD
-        mode = g_place;                                     // 1 or 2
+        mode = env->place;                                  // 1 or 2
         B = (mode == 1) ? (int)((waves + W - 1) / W) : (int)cus;
     } else if (waves > 8 * cus) {                           // several rounds
         mode = 3;
@@ -2184,8 +2185,8 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
     // np.linspace: step = (stop - start) / (num - 1); y = arange(num) * step + start; y[-1] = stop
     a.save_step = (S > 1) ? (receiver_range - source_range) / (double)(S - 1) : 0.0;
     a.save_formula = (flags & PGR_SAVE_LINSPACE) ? 1 : 0;
-    a.park_lanes = g_park_lanes;
-    a.park_trips = g_park_trips;
+    a.park_lanes = env->park_lanes;
+    a.park_trips = env->park_trips;
     a.max_steps = max_steps; a.flags = flags;
 
     int64_t waves = (N + 63) / 64;
@@ -2200,8 +2201,8 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
     int zm = D.z_simple ? ((D.dz == 1.0) ? 4 : 1) : 0;
     const size_t zq_bytes = (size_t)D.nz * sizeof(double);
     size_t zx_bytes = 0;  // LDS taken by the depth search of the chosen variant
-    if (!D.z_simple && g_depth_search != 1) {
-        if (D.z_quad && g_depth_search == 0) {
+    if (!D.z_simple && env->depth_search != 1) {
+        if (D.z_quad && env->depth_search == 0) {
             if (env->range_indep && tab_bytes + zq_bytes <= env->max_lds) { lds_tab = true; zm = 3; zx_bytes = zq_bytes; }
             else if (zq_bytes <= env->max_lds) { lds_tab = false; zm = 3; zx_bytes = zq_bytes; }
         }
@@ -2216,7 +2217,7 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
     if (lds_tab) {
         // one workgroup per CU (the LDS table is per workgroup): the smallest workgroup that
         // covers the fan in a single round, capped at 8 waves
-        wpb = g_waves_per_block;
+        wpb = env->waves_per_block;
         if (wpb == 0) {
             wpb = (int)((waves + env->num_cus - 1) / env->num_cus);
             if (wpb < 1) wpb = 1;
@@ -2228,7 +2229,7 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
         if (schedule_waves(env, y0, N, waves, wpb, st, a.wave_map, blocks)) return -1;
         lds = tab_bytes + zx_bytes;
     } else {
-        wpb = g_waves_per_block ? g_waves_per_block : 4;
+        wpb = env->waves_per_block ? env->waves_per_block : 4;
         blocks = (waves + wpb - 1) / wpb;
         // the same scheduling; a fan too small for it keeps 4-wave workgroups
         if (waves > 4 * (int64_t)env->num_cus) {
@@ -2293,8 +2294,9 @@ __global__ void pgr_gather_cols(const double* __restrict__ src, double* __restri
     dst[s * M + m] = src[s * N + idx[m]];
 }
 
-// Touch (write) one byte of every page of the output buffers from up to 16 threads.  The buffers
-// are outputs that the following copies overwrite completely.
+// Fault in every page of the caller's output buffers from up to 16 threads: each page's first byte is
+// read and written back UNCHANGED (a write access, so the page is really allocated, but nothing the
+// caller may still want -- a reused buffer whose tail the copies below do not overwrite -- is altered).
 static void prefault_outputs(std::initializer_list<double*> bufs, size_t bytes)
 {
     const size_t page = 4096;
@@ -2311,7 +2313,10 @@ static void prefault_outputs(std::initializer_list<double*> bufs, size_t bytes)
             th.emplace_back([base, bytes, p0, p1, page]() {
                 for (size_t q = p0; q < p1; q++) {
                     size_t o = q * page;
-                    if (o < bytes) ((volatile char*)base)[o] = 0;
+                    if (o < bytes) {
+                        volatile char* c = (volatile char*)base + o;
+                        *c = *c;
+                    }
                 }
             });
         }
@@ -2354,8 +2359,13 @@ extern "C" int pgr_shoot_fan(pgr_env* env, const double* y0, int64_t N, double s
         pgr_env* e;
         ~Trim() { if (e->ws_bytes > ((size_t)16 << 30)) { (void)hipFree(e->ws); e->ws = nullptr; e->ws_bytes = 0; } }
     } trim{env};
-    HIPCHK(hipMemcpy(dy0.p, y0, N * 3 * sizeof(double), hipMemcpyHostToDevice));
-    if (save) HIPCHK(hipMemcpy(dr.p, r_save, (size_t)S * sizeof(double), hipMemcpyHostToDevice));
+    // everything of this call goes through the environment's own stream and waits for THAT stream only
+    // (not the device: other streams of the process -- another environment's fan, a framework's copies --
+    // are none of its business)
+    if (!env->stream) HIPCHK(hipStreamCreateWithFlags(&env->stream, hipStreamNonBlocking));
+    hipStream_t st = env->stream;
+    HIPCHK(hipMemcpyAsync(dy0.p, y0, N * 3 * sizeof(double), hipMemcpyHostToDevice, st));
+    if (save) HIPCHK(hipMemcpyAsync(dr.p, r_save, (size_t)S * sizeof(double), hipMemcpyHostToDevice, st));
     if (save) {
         // is r_save exactly np.linspace(source_range, receiver_range, S)?  then the kernel
         // recomputes it per index instead of loading it
@@ -2374,14 +2384,15 @@ extern "C" int pgr_shoot_fan(pgr_env* env, const double* y0, int64_t N, double s
                                   save ? (double*)dT.p : nullptr, save ? (double*)dZ.p : nullptr,
                                   save ? (double*)dP.p : nullptr, (double*)dE.p, (int32_t*)dnb.p,
                                   (int32_t*)dns.p, (int32_t*)dst.p, (int32_t*)dn1.p, (int32_t*)dn2.p,
-                                  nullptr);
+                                  (void*)st);
     if (rc) return rc;
     // While the kernel runs: fault in the caller's (typically fresh, untouched) output buffers on
     // several threads.  A D2H copy into untouched pageable memory runs at the page-fault rate of
     // one thread (15 GB/s measured), into touched memory at 56 GB/s (scripts/probes/pcie_probe.py).
     if (save && ns_bytes >= ((size_t)32 << 20)) prefault_outputs({T, z, p}, ns_bytes);
-    HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(status, dst.p, N * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipMemcpyAsync(status, dst.p, N * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
     bool squeezed = false;
     if (save && (flags & PGR_COMPACT)) {
         if (!(flags & PGR_SAMPLE_MAJOR)) return fail("pgr_shoot_fan: PGR_COMPACT needs PGR_SAMPLE_MAJOR");
@@ -2397,28 +2408,30 @@ extern "C" int pgr_shoot_fan(pgr_env* env, const double* y0, int64_t N, double s
             if (M > 0) {
                 HIPCHK(hipMalloc(&tmp.p, (size_t)S * (size_t)M * sizeof(double)));
                 HIPCHK(hipMalloc(&didx.p, (size_t)M * sizeof(int)));
-                HIPCHK(hipMemcpy(didx.p, keep.data(), (size_t)M * sizeof(int), hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpyAsync(didx.p, keep.data(), (size_t)M * sizeof(int), hipMemcpyHostToDevice, st));
                 double* host[3] = {T, z, p};
                 void* dev[3] = {dT.p, dZ.p, dP.p};
                 for (int a3 = 0; a3 < 3; a3++) {
                     hipLaunchKernelGGL(pgr_gather_cols, dim3((unsigned)((M + 255) / 256), (unsigned)S), dim3(256), 0,
-                                       nullptr, (const double*)dev[a3], (double*)tmp.p, (const int*)didx.p, M, N);
+                                       st, (const double*)dev[a3], (double*)tmp.p, (const int*)didx.p, M, N);
                     HIPCHK(hipGetLastError());
-                    HIPCHK(hipMemcpy(host[a3], tmp.p, (size_t)S * (size_t)M * sizeof(double), hipMemcpyDeviceToHost));
+                    HIPCHK(hipMemcpyAsync(host[a3], tmp.p, (size_t)S * (size_t)M * sizeof(double), hipMemcpyDeviceToHost, st));
+                    HIPCHK(hipStreamSynchronize(st));  // tmp is reused by the next array
                 }
             }
         }
     }
     if (save && !squeezed) {
-        HIPCHK(hipMemcpy(T, dT.p, ns_bytes, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(z, dZ.p, ns_bytes, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(p, dP.p, ns_bytes, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpyAsync(T, dT.p, ns_bytes, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(z, dZ.p, ns_bytes, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(p, dP.p, ns_bytes, hipMemcpyDeviceToHost, st));
     }
-    if (end_state) HIPCHK(hipMemcpy(end_state, dE.p, N * 3 * sizeof(double), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(n_bott, dnb.p, N * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(n_surf, dns.p, N * 4, hipMemcpyDeviceToHost));
-    if (n_steps) HIPCHK(hipMemcpy(n_steps, dn1.p, N * 4, hipMemcpyDeviceToHost));
-    if (n_rej) HIPCHK(hipMemcpy(n_rej, dn2.p, N * 4, hipMemcpyDeviceToHost));
+    if (end_state) HIPCHK(hipMemcpyAsync(end_state, dE.p, N * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(n_bott, dnb.p, N * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(n_surf, dns.p, N * 4, hipMemcpyDeviceToHost, st));
+    if (n_steps) HIPCHK(hipMemcpyAsync(n_steps, dn1.p, N * 4, hipMemcpyDeviceToHost, st));
+    if (n_rej) HIPCHK(hipMemcpyAsync(n_rej, dn2.p, N * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
     return 0;
 }
 

@@ -15,14 +15,14 @@ y0 = y0_for(oracle, arrs, 700.0, 5e3, np.linspace(-18, 18, 130))
 o = oracle.shoot_fan(*arrs, y0, 5e3, 140e3, 136)
 env = _lib.EnvHandle(*arrs)
 for label, kw, park in (("default", {}, (64, 64)), ("exact", dict(exact_bisection=True), (64, 64)), ("nopark", {}, (1, 0))):
-    _lib.set_park(*park)
+    env.set_option("park", *park)
     g = env.shoot_fan(y0, 5e3, 140e3, 136, **kw)
     d = np.abs(g["T"] - o["T"]); d[np.abs(o["xi"]) > 8] = 0
     bad = np.argwhere(d > 1e-5)
     print(label, "status eq", np.array_equal(g["status"], o["status"]), "nb eq", np.array_equal(g["n_bott"], o["n_bott"]), "ns eq", np.array_equal(g["n_surf"], o["n_surf"]), "n bad samples", len(bad), "rays", np.unique(bad[:, 0])[:20])
     for (i, j) in bad[:6]:
         print("   ray", i, "sample", j, "r", o["r"][j], "T gpu/orc", g["T"][i, j], o["T"][i, j], "z", g["z"][i, j], o["z"][i, j], "xi", o["xi"][i, j], "nb/ns", o["n_bott"][i], o["n_surf"][i], "steps", g["n_steps"][i], o["n_steps"][i])
-_lib.set_park(64, 64)
+env.set_option("park", 64, 64)
 g = env.shoot_fan(y0, 5e3, 140e3, 136)
 d = np.abs(g["T"] - o["T"]); d[np.abs(o["xi"]) > 8] = 0
 i, j = np.unravel_index(np.nanargmax(d), d.shape)

@@ -28,14 +28,14 @@ if a.lib:
 arrs = munk_arrays(a.km * 1e3, nr=(101 if a.slope else 100), sofar_slope=a.slope)
 env = _lib.EnvHandle(*arrs)
 if a.place >= 0:
-    _lib.set_placement(a.place)
+    env.set_option("placement", a.place)
 theta = np.linspace(a.amin, a.amax, a.rays)
 y0 = fan_y0(arrs, 1000.0, 0.0, -theta)
 for mode in a.modes:
     fan = DeviceFan(env, y0, 0.0, a.km * 1e3, a.S, save=(mode != "nosave"), sample_major=(mode == "sample"), exact_bisection=a.exact, exact_samples=a.exact_samples)
     for w, (pl, pt) in [(w, pp) for w in a.wpb for pp in zip(a.park[0::2], a.park[1::2])]:
-        _lib.set_waves_per_block(w)
-        _lib.set_park(pl, pt)
+        env.set_option("waves_per_block", w)
+        env.set_option("park", pl, pt)
         fan.run(); torch.cuda.synchronize()
         ts = []
         for _ in range(a.reps):

@@ -8,7 +8,7 @@ from pygenray_amd.device_fan import DeviceFan, fan_y0
 arrs = munk_arrays(1000e3); env = _lib.EnvHandle(*arrs)
 theta = np.linspace(-20, 20, 100000); y0 = fan_y0(arrs, 1000.0, 0.0, -theta)
 for park in ((64, 64), (64, 16), (56, 64), (60, 64)):
-    _lib.set_park(*park)
+    env.set_option("park", *park)
     fan = DeviceFan(env, y0, 0.0, 1000e3, 2, save=False); fan.run(); torch.cuda.synchronize()
     att = (fan.n_steps + fan.n_rej).cpu().numpy().astype(np.int64)
     fan.flags |= 16; fan.run(); torch.cuda.synchronize()
@@ -20,7 +20,7 @@ for park in ((64, 64), (64, 16), (56, 64), (60, 64)):
         print(park, name, "trips", trips[lo:hi].mean().round(), "max-lane attempts", mx[lo:hi].mean().round(), "mean-lane attempts", mean[lo:hi].mean().round(), "services", serv[lo:hi].mean().round(), "exact-bisection fallbacks per wave (62 lanes)", fb[lo:hi].sum(1).mean().round(1), "overhead trips/max", (trips[lo:hi] / mx[lo:hi]).mean().round(3))
 print("---- whole-fan maxima")
 for park in ((64, 64), (64, 16), (64, 8), (64, 4)):
-    _lib.set_park(*park)
+    env.set_option("park", *park)
     fan = DeviceFan(env, y0, 0.0, 1000e3, 2, save=False); fan.run(); torch.cuda.synchronize()
     att = (fan.n_steps + fan.n_rej).cpu().numpy().astype(np.int64)
     fan.flags |= 16; fan.run(); torch.cuda.synchronize()

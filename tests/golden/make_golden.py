@@ -414,11 +414,109 @@ def g9_irregular_grids():
     save("g9_irregular_grids.npz", theta_ode=theta, **pack_env(arrs), **out)
 
 
+def g10_eigenrays_1000km():
+    """BASELINE configs[3] at reference speed: the config-1 environment to 1000 km, launch angles on
+    the 1e6-angle grid linspace(-20, 20, 1_000_000).  The reference cannot shoot 1e6 rays (0.4 s
+    each), so: the C oracle (test infrastructure, oracle/) scans every 500th grid angle for sign
+    changes of z_end + receiver_depth and bisects on the grid index down to the adjacent pair; the
+    REFERENCE then shoots windows of 48 consecutive grid angles around three of those brackets (a
+    near-axial one, a refracted one, a surface/bottom-reflected one) and runs its own
+    _find_single_eigenray (eigenrays.py:206-268) on each, with every trial angle recorded."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    import oracle
+    z = np.arange(0, 6000, 1.0)
+    env = munk_env(1000e3, 100, z)
+    arrs = env_arrays(env)
+    N = 1_000_000
+    grid = np.linspace(-20, 20, N)
+    rd, zs, x1 = 1000.0, 1000.0, 1000e3
+    c0 = pr.bilinear_interp(0.0, zs, arrs[2], arrs[3], arrs[0])
+
+    def zend(idx):
+        th = -grid[np.asarray(idx)]                     # ODE angle = -user (>= 70-ray branch)
+        y0 = np.stack([np.zeros(len(th)), np.full(len(th), zs), np.sin(np.radians(th)) / c0], 1)
+        o = oracle.shoot_fan(*arrs, y0, 0.0, x1, 2)
+        return np.where(o["status"] == 0, -o["z"][:, -1], np.nan)   # stored convention
+
+    coarse = np.arange(0, N, 500)
+    zc = zend(coarse)
+    sg = np.sign(zc + rd)
+    cand = np.where((np.diff(sg) != 0) & np.isfinite(zc[:-1]) & np.isfinite(zc[1:]))[0]
+    print(f"  {len(cand)} sign changes on the 500-stride scan")
+    picks = []
+    for want in (0.3, 8.0, 15.5):                        # |angle| of the brackets to keep
+        k = cand[np.argmin(np.abs(np.abs(grid[coarse[cand]]) - want))]
+        lo, hi = int(coarse[k]), int(coarse[k + 1])
+        slo = np.sign(zend([lo])[0] + rd)
+        while hi - lo > 1:                               # bisect on the grid index
+            mid = (lo + hi) // 2
+            if np.sign(zend([mid])[0] + rd) == slo:
+                lo = mid
+            else:
+                hi = mid
+        picks.append(lo)
+    print("  brackets start at grid indices", picks, "angles", grid[picks])
+    W = 48
+    out = dict(n_grid=N, receiver_depth=rd, source_depth=zs, receiver_range=x1, window=W)
+    log = []
+    orig = pr.shoot_ray
+
+    def logged(source_depth, source_range, launch_angle, *a, **k):
+        log.append(float(launch_angle))
+        return orig(source_depth, source_range, launch_angle, *a, **k)
+
+    for j, s0 in enumerate(picks):
+        idx = np.arange(s0 - W // 2 + 1, s0 + W // 2 + 1)
+        la = -grid[idx]
+        t0 = time.time()
+        o = shoot_array_level(arrs, zs, 0.0, x1, la, 2)
+        print(f"  window {j}: {len(idx)} reference rays in {time.time() - t0:.0f} s")
+        zs_end, ts_end = -o["z"][:, -1], o["T"][:, -1]
+        depth_sign = np.sign(zs_end + rd)
+        starts = np.where(np.diff(depth_sign))[0]
+        assert len(starts) >= 1 and (s0 - idx[0]) in starts, (starts, s0 - idx[0])
+        b = s0 - idx[0]
+        z1, z2, t1, t2 = zs_end[b], zs_end[b + 1], grid[idx[b]], grid[idx[b + 1]]
+        rft = t1 - (z1 + rd) * (t2 - t1) / (z2 - z1)
+        del log[:]
+        pr.shoot_ray = logged
+        try:
+            ray = er._find_single_eigenray((0, z1, z2, t1, t2, rft, rd, zs, 0.0, x1, 2, env, 1, 20,
+                                            dict(debug=False, flatearth=False)))
+        finally:
+            pr.shoot_ray = orig
+        res = [np.nan] * 6 if ray is None else [ray.launch_angle, ray.t[-1], ray.z[-1], ray.p[-1], ray.n_bottom, ray.n_surface]
+        out.update({f"w{j}_idx": idx, f"w{j}_z_end": zs_end, f"w{j}_t_end": ts_end, f"w{j}_ok": o["ok"],
+                    f"w{j}_n_bott": o["n_bott"], f"w{j}_n_surf": o["n_surf"], f"w{j}_bracket": b,
+                    f"w{j}_starts": starts, f"w{j}_theta_seq": np.array(log), f"w{j}_eigen": np.array(res, float)})
+        print(f"    bracket at window position {b}; trial angles {len(log)}; eigenray {res[:3]}")
+        # the same root from a COARSE bracket (a fan 500 times coarser: 0.02 degrees between the ends), so
+        # that the false-position iteration takes several trial rays: the whole theta sequence is recorded
+        ic = np.array([s0 - 250, s0 + 251])
+        oc = shoot_array_level(arrs, zs, 0.0, x1, -grid[ic], 2)
+        zc1, zc2 = -oc["z"][0, -1], -oc["z"][1, -1]
+        if np.sign(zc1 + rd) != np.sign(zc2 + rd):
+            tc1, tc2 = grid[ic[0]], grid[ic[1]]
+            rftc = tc1 - (zc1 + rd) * (tc2 - tc1) / (zc2 - zc1)
+            del log[:]
+            pr.shoot_ray = logged
+            try:
+                rayc = er._find_single_eigenray((0, zc1, zc2, tc1, tc2, rftc, rd, zs, 0.0, x1, 2, env, 1, 20,
+                                                 dict(debug=False, flatearth=False)))
+            finally:
+                pr.shoot_ray = orig
+            resc = [np.nan] * 6 if rayc is None else [rayc.launch_angle, rayc.t[-1], rayc.z[-1], rayc.p[-1], rayc.n_bottom, rayc.n_surface]
+            out.update({f"w{j}_coarse_idx": ic, f"w{j}_coarse_z": np.array([zc1, zc2]), f"w{j}_coarse_theta_seq": np.array(log),
+                        f"w{j}_coarse_eigen": np.array(resc, float)})
+            print(f"    coarse bracket: trial angles {len(log)}; eigenray {resc[:3]}")
+    save("g10_eigenrays_1000km.npz", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     table = dict(g1=g1_fixture_case, g2=g2_munk_100km, g3=g3_munk_1000km, g4=g4_range_dependent,
                  g5=g5_analytic_envs, g6=g6_eigenrays, g7=g7_unit_vectors, g8=g8_timing,
-                 g9=g9_irregular_grids)
+                 g9=g9_irregular_grids, g10=g10_eigenrays_1000km)
     for w in which:
         print(w)
         table[w]()

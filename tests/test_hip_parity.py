@@ -290,10 +290,10 @@ def test_layouts_and_end_state_only(lib):
     assert c["T"] is None
     # every workgroup shape gives identical results (rays are independent)
     for w in (1, 3, 8):
-        lib.set_waves_per_block(w)
+        env.set_option("waves_per_block", w)
         d = env.shoot_fan(y0, 0.0, 100e3, 64)
         assert np.array_equal(a["z"], d["z"]) and np.array_equal(a["status"], d["status"])
-    lib.set_waves_per_block(0)
+    env.set_option("waves_per_block", 0)
     # no sentinel survives: every sample of an OK ray is written
     assert np.all(np.isfinite(a["T"][a["status"] == 0]))
     # empty fan and argument errors
@@ -332,10 +332,10 @@ def test_bucketed_depth_search_equals_binary_search(lib):
         a = env.shoot_fan(y0, 0.0, 200e3, 41)           # automatic: index polynomial or bucket table
         for mode in (1, 2):                              # binary search; bucket table
             try:
-                lib.set_depth_search(mode)
+                env.set_option("depth_search", mode)
                 b = env.shoot_fan(y0, 0.0, 200e3, 41)
             finally:
-                lib.set_depth_search(0)
+                env.set_option("depth_search", 0)
             for k in ("T", "z", "p", "end"):
                 assert np.array_equal(a[k], b[k], equal_nan=True), (mode, k)
             for k in ("status", "n_steps", "n_rej", "n_bott", "n_surf"):
@@ -389,6 +389,26 @@ def test_compact_and_stored_sign_flags(lib):
     assert c["T"].shape == (33, 150) and np.array_equal(c["z"], a["z"][:, :150])
 
 
+def test_reused_output_buffers_keep_what_the_call_does_not_write(lib):
+    """The host entry faults the caller's output pages in while the kernel runs (pgr_shoot_fan); with
+    PGR_COMPACT and dropped rays only [S][M] of the caller's [S][N] buffers is written, and the tail
+    of a REUSED buffer must come back untouched (it used to lose the first byte of every page)."""
+    arrs = munk_arrays(100e3)
+    th = np.concatenate([np.linspace(-19, 19, 69_000), np.full(1000, 89.9999)])   # 1000 rays are dropped
+    y0 = y0_for(oracle, arrs, 1000.0, 0.0, th)
+    env = lib.EnvHandle(*arrs)
+    N, S = len(th), 64                                   # 35.8 MB per array: above the prefault threshold
+    bufs = [np.full((S, N), 7.25) for _ in range(3)]
+    out = env.shoot_fan(y0, 0.0, 100e3, S, sample_major=True, compact=True, buffers=bufs)
+    M = int((out["status"] == 0).sum())
+    assert 0 < M < N and out["T"].shape == (S, M)
+    for b in bufs:
+        assert np.all(b.reshape(-1)[S * M:] == 7.25)
+    ref = env.shoot_fan(y0, 0.0, 100e3, S, sample_major=True, compact=True)
+    assert np.array_equal(out["z"], ref["z"])
+    env.close()
+
+
 def test_sample_evaluation_orders_agree(lib):
     """Default (stage-major FMA) and PGR_EXACT_SAMPLES (SciPy's Q = K.T @ P order) evaluate
     the SAME quartics of the SAME integration: steps, end states and the exact last column are
@@ -424,11 +444,11 @@ def test_full_size_config1_properties(lib):
     y0 = y0_for(oracle, arrs, 1000.0, 0.0, -theta)
     env = lib.EnvHandle(*arrs)
     a = env.shoot_fan(y0, 0.0, 1000e3, 101)
-    lib.set_placement(0)  # cost-aware wave scheduling off: same rays, same bits, different SIMDs
+    env.set_option("placement", 0)  # cost-aware wave scheduling off: same rays, same bits, different SIMDs
     b = env.shoot_fan(y0, 0.0, 1000e3, 101)
-    lib.set_placement(1)
+    env.set_option("placement", 1)
     b1 = env.shoot_fan(y0[:80000], 0.0, 1000e3, 3)
-    lib.set_placement(2)
+    env.set_option("placement", 2)
     b2 = env.shoot_fan(y0[:80000], 0.0, 1000e3, 3)
     assert np.array_equal(b1["end"], b2["end"], equal_nan=True) and np.array_equal(b1["end"], a["end"][:80000], equal_nan=True)
     assert np.array_equal(a["end"], b["end"], equal_nan=True) and np.array_equal(a["n_steps"], b["n_steps"])
@@ -668,23 +688,25 @@ def test_wave_scheduler_is_a_pure_permutation(lib):
     sizes = [4 * cus * 64 + 1, 5 * cus * 64, 7 * cus * 64 - 63, 8 * cus * 64, 8 * cus * 64 + 1, 150_000]
     for n in sizes:
         y0 = y0_for(oracle, arrs, 900.0, 0.0, np.linspace(-19, 19, n))
-        lib.set_placement(0)
+        env.set_option("placement", 0)
         ref = env.shoot_fan(y0, 0.0, 60e3, 1, save=False)
         for mode in (1, 2):
-            lib.set_placement(mode)
+            env.set_option("placement", mode)
             got = env.shoot_fan(y0, 0.0, 60e3, 1, save=False)
             assert np.array_equal(got["end"], ref["end"], equal_nan=True), (n, mode)
             assert np.array_equal(got["n_steps"], ref["n_steps"]) and np.array_equal(got["status"], ref["status"])
-    lib.set_placement(2)
-    # range-dependent (no LDS table) path as well
+    env.set_option("placement", 2)
+    # range-dependent (no LDS table) path as well; options belong to an environment: env's do not leak into env2
     arrs2 = munk_arrays(60e3, nr=13, sofar_slope=1e-3)
     env2 = lib.EnvHandle(*arrs2)
     y0 = y0_for(oracle, arrs2, 900.0, 0.0, np.linspace(-19, 19, 90_000))
-    lib.set_placement(0)
+    env2.set_option("placement", 0)
     ref = env2.shoot_fan(y0, 0.0, 60e3, 1, save=False)
-    lib.set_placement(2)
+    env2.set_option("placement", 2)
     got = env2.shoot_fan(y0, 0.0, 60e3, 1, save=False)
     assert np.array_equal(got["end"], ref["end"], equal_nan=True) and np.array_equal(got["status"], ref["status"])
+    with pytest.raises(lib.PgrError):
+        env2.set_option("park", 0, 5)
 
 
 def test_plain_c_example_runs(lib, tmp_path):
@@ -706,3 +728,111 @@ def test_plain_c_example_runs(lib, tmp_path):
         assert int(st) == o["status"][k] == 0
         assert abs(float(T) - o["T"][k, -1]) < 1e-8 * 70 and abs(float(z) - o["z"][k, -1]) < 2e-5
         assert abs(int(nsteps) - o["n_steps"][k]) <= 2
+
+
+# ------------------------------------------------------------------ BASELINE configs[3] and configs[4] at full size
+def _config1_env(pr):
+    z = np.arange(0, 6000, 1.0)
+    r = np.linspace(0.0, 1000e3, 100)
+    return pr.OceanEnvironment2D(pr.DataArray(np.tile(pr.munk_ssp(z), (100, 1)), dims=["range", "depth"], coords={"range": r, "depth": z}),
+                                 pr.DataArray(np.full(100, 5000.0), dims=["range"], coords={"range": r}), flat_earth_transform=False)
+
+
+def test_config3_eigenray_search_on_the_1e6_angle_fan(lib):
+    """BASELINE configs[3]: fixed source / receiver, a fan of 1 000 000 launch angles (end state only)
+    and pygenray's regula falsi on every bracket, through the drop-in API.  Checked against (i) the
+    oracle, bit for bit, on every 1000th ray of the fan; (ii) the REFERENCE's own rays on three
+    48-angle windows of the same grid (golden g10): end depths, arrival times, bracket positions;
+    (iii) the reference's _find_single_eigenray on those three brackets and on 500 times coarser
+    brackets around them: launch angle, arrival time, end depth of the eigenray."""
+    import pygenray_amd as pr
+    from pygenray_amd.eigenrays import _regula_falsi_batch
+    g = load("g10_eigenrays_1000km.npz")
+    N, rd, zs, x1 = int(g["n_grid"]), float(g["receiver_depth"]), float(g["source_depth"]), float(g["receiver_range"])
+    env = _config1_env(pr)
+    grid = np.linspace(-20, 20, N)
+    fan = pr.shoot_rays(zs, 0.0, grid, x1, 2, env, debug=False, flatearth=False)
+    assert N - 2000 < len(fan) <= N                      # the near-vertical-free fan loses only a few rays (Q12)
+    pos = np.searchsorted(fan.thetas, grid)              # grid index -> position in the fan (dropped rays vanish)
+    alive = (pos < len(fan)) & (fan.thetas[np.minimum(pos, len(fan) - 1)] == grid)
+    # (i) every 1000th ray against the oracle
+    sub = np.arange(0, N, 1000)
+    arrs = pr._unpack_envi(env, flatearth=False)
+    y0 = y0_for(oracle, arrs, zs, 0.0, -grid[sub])
+    o = oracle.shoot_fan(*arrs, y0, 0.0, x1, 2, math=oracle.MATH_CR)
+    assert np.array_equal(o["status"] == 0, alive[sub])
+    ok = o["status"] == 0
+    same = (fan.ts[pos[sub][ok], -1] == o["T"][ok, -1]) & (-fan.zs[pos[sub][ok], -1] == o["z"][ok, -1])
+    assert same.mean() >= 0.999, same.mean()
+    assert np.array_equal(fan.n_botts[pos[sub][ok]], o["n_bott"][ok]) and np.array_equal(fan.n_surfs[pos[sub][ok]], o["n_surf"][ok])
+    # (ii) the reference's rays on three windows of the grid
+    for j in range(3):
+        idx = g[f"w{j}_idx"]
+        assert np.all(alive[idx]) and np.all(g[f"w{j}_ok"] == 1)
+        # (the reference's own rays: NumPy / SciPy arithmetic, chaotic at the last bit over 1000 km --
+        # policy (B) of helpers.py: the median within 1e-8 of the water column, no ray beyond 1e-6)
+        dz = np.abs(fan.zs[pos[idx], -1] - g[f"w{j}_z_end"]) / 5000.0
+        assert np.median(dz) <= 1e-8 and dz.max() <= 1e-6, (j, np.median(dz), dz.max())
+        np.testing.assert_allclose(fan.ts[pos[idx], -1], g[f"w{j}_t_end"], rtol=0, atol=1e-6)
+        assert np.array_equal(fan.n_botts[pos[idx]], g[f"w{j}_n_bott"]) and np.array_equal(fan.n_surfs[pos[idx]], g[f"w{j}_n_surf"])
+        assert np.array_equal(np.where(np.diff(np.sign(fan.zs[pos[idx], -1] + rd)))[0], g[f"w{j}_starts"])
+    # (iii) the search itself
+    er = pr.find_eigenrays(fan, [rd], zs, 0.0, x1, 2, env, ztol=1, max_iter=20, debug=False, flatearth=False, quiet=True)
+    n_br = int(np.count_nonzero(np.diff(np.sign(fan.zs[:, -1] + rd))))
+    assert er.num_eigenrays[rd] == n_br and 60 <= n_br <= 120
+    assert er.num_eigenrays_found[0] + len(er.failed_eray_theta_brackets[0]) == n_br
+    assert er.num_eigenrays_found[0] >= 0.9 * n_br
+    assert np.all(np.abs(er.zs[0][:, -1] + rd) < 1.0)
+    for j in range(3):
+        ref = g[f"w{j}_eigen"]
+        k = int(np.argmin(np.abs(er.launch_angles[0] - ref[0])))
+        assert abs(er.launch_angles[0][k] - ref[0]) < 1e-8          # the first false-position angle hits: same angle
+        assert abs(er.ts[0][k, -1] - ref[1]) < 1e-6 and abs(er.zs[0][k, -1] - ref[2]) < 5e-3
+        assert (int(er.n_botts[0][k]), int(er.n_surfs[0][k])) == (int(ref[4]), int(ref[5]))
+        # the 500 times coarser bracket around it (the ends are fan rays 501 grid steps apart)
+        ic = g[f"w{j}_coarse_idx"]
+        z12 = fan.zs[pos[ic], -1]
+        np.testing.assert_allclose(z12, g[f"w{j}_coarse_z"], rtol=0, atol=5e-3)
+        found, th, r, T, Z, P, nb, ns = _regula_falsi_batch(z12[:1], z12[1:], grid[ic[:1]], grid[ic[1:]], rd, zs, 0.0, x1, 2, env,
+                                                            1, 20, dict(debug=False, flatearth=False, quiet=True))
+        refc = g[f"w{j}_coarse_eigen"]
+        assert found[0] and abs(th[0] - refc[0]) < 1e-7 and abs(T[0, -1] - refc[1]) < 1e-6 and abs(Z[0, -1] - refc[2]) < 5e-3
+
+
+def test_config4_end_records_and_arrival_time_histogram_of_1e6_rays(lib):
+    """BASELINE configs[4], one GPU's share: 1 000 000 rays, end state only, the kernel writes the
+    40-byte end records of the all-gather (PGR_PACKED_END); the 4096-bin arrival-time histogram on the
+    device (pgr_arrival_histogram_device, read straight from the records) equals np.histogram of the
+    same end states count for count; the single-rank all-gather hands the fan back in launch order."""
+    import torch
+    from pygenray_amd.device_fan import DeviceFan, fan_y0
+    from pygenray_amd.distributed import start_all_gather_records, arrival_time_histogram
+    arrs = munk_arrays(1000e3)
+    n = 1_000_000
+    y0 = fan_y0(arrs, 1000.0, 0.0, -np.linspace(-20, 20, n))
+    env = lib.EnvHandle(*arrs)
+    fan = DeviceFan(env, y0, 0.0, 1000e3, 2, save=False, packed_end=True, n_pad=n)
+    fan.run()
+    torch.cuda.synchronize()
+    t_end = fan.records[:n, 0]
+    bins, lo, hi = 4096, 1000e3 / 1560.0, 1000e3 / 1400.0
+    h = arrival_time_histogram(t_end, fan.status, bins, lo, hi).cpu().numpy()
+    st = fan.status.cpu().numpy()
+    T = fan.records[:n, 0].cpu().numpy()
+    want = np.histogram(T[(st == 0) & ~np.isnan(T)], bins=bins, range=(lo, hi))[0]
+    assert np.array_equal(h, want) and h.sum() > 0.99 * n
+    # the records carry the same end states, counts and status as the plain outputs of an unpacked run
+    plain = DeviceFan(env, y0, 0.0, 1000e3, 2, save=False)
+    plain.run()
+    end, nb, ns, stg = start_all_gather_records(fan.records, n).finish()
+    torch.cuda.synchronize()
+    assert torch.equal(stg, plain.status) and torch.equal(nb, plain.n_bott) and torch.equal(ns, plain.n_surf)
+    ok = plain.status == 0
+    assert torch.equal(end[ok], plain.end[ok]) and bool(torch.isnan(end[~ok]).all())
+    # a strided oracle subset pins the end states the histogram was built from
+    sub = np.arange(0, n, 2500)
+    o = oracle.shoot_fan(*arrs, y0[sub], 0.0, 1000e3, 2, math=oracle.MATH_CR)
+    okk = o["status"] == 0
+    assert np.array_equal(okk, st[sub] == 0)
+    assert np.mean(T[sub][okk] == o["T"][okk, -1]) >= 0.995
+    env.close()
