@@ -40,6 +40,15 @@
 #define pgr_cr_asin(x) asin(x)
 #define pgr_cr_sin(x) sin(x)
 #define pgr_cr_pow_p02(x) pow((x), 0.2)
+#define PGR_ASIN_DD_T double
+#define PGR_ASIN_DD(v) asin(v)
+#define PGR_ASIN_DD_HI(a) (a)
+#define PGR_SIN_REFLECT(x, v, a) sin(x)
+#else
+#define PGR_ASIN_DD_T struct pgr_dd
+#define PGR_ASIN_DD(v) pgr_cr_asin_dd(v)
+#define PGR_ASIN_DD_HI(a) ((a).h)
+#define PGR_SIN_REFLECT(x, v, a) pgr_cr_sin_near_minus_asin((x), (v), (a))
 #endif
 
 // ------------------------------------------------------------------------------------
@@ -63,6 +72,7 @@ struct EnvDev {
     double r0, dr, inv_dr;
     double b0, db, inv_db;
     double zlo_tol, zhi_tol, rlo_tol, rhi_tol;  // bbox bounds -+ 1e-6 (REF/integration_processes.py:295-302)
+    double c_lo, c_hi;  // min and max of the sound-speed table (c_hi with a 1e-3 margin): |p| c_hi < 1 settles |p c| <= 1 without a look-up
     // bucketed depth search for non-uniform zin (e.g. the flat-earth transformed grid): zbucket[k]
     // = the cell index at the lower edge of uniform bin k of width zb_w <= 0.9 min(diff(zin)), so
     // the cell of any z in bin k is zbucket[k] or zbucket[k] + 1 (host verified)
@@ -374,6 +384,7 @@ struct Ctx {
     // descriptor is read from memory where it is needed)
     const double h_inv_dz, h_dz, h_r0, h_dr, h_inv_dr;
     const double h_b_zmin, h_b_xlo, h_b_xhi, h_zhi_tol, h_zlo_tol, h_rlo_tol, h_rhi_tol;  // events()
+    const double h_c_lo, h_c_hi;
     const double h_b0, h_db, h_inv_db;  // bathy()
     const int h_nb, h_b_uniform;
     const double2* const h_tab;  // HBM table variant
@@ -394,7 +405,7 @@ struct Ctx {
           h_zq_c0(e_.zq_c0), h_zq_c1(e_.zq_c1), h_zq_c2(e_.zq_c2), h_zq_inv_span(e_.zq_inv_span),
           h_inv_dz(e_.inv_dz), h_dz(e_.dz), h_r0(e_.r0), h_dr(e_.dr),
           h_b_zmin(e_.b_zmin), h_b_xlo(e_.b_xlo), h_b_xhi(e_.b_xhi), h_zhi_tol(e_.zhi_tol),
-          h_zlo_tol(e_.zlo_tol), h_rlo_tol(e_.rlo_tol), h_rhi_tol(e_.rhi_tol), h_b0(e_.b0), h_db(e_.db),
+          h_zlo_tol(e_.zlo_tol), h_rlo_tol(e_.rlo_tol), h_rhi_tol(e_.rhi_tol), h_c_lo(e_.c_lo), h_c_hi(e_.c_hi), h_b0(e_.b0), h_db(e_.db),
           h_inv_db(e_.inv_db), h_nb(e_.nb), h_b_uniform(e_.b_uniform), h_tab(e_.tab),
           h_row_stride(e_.row_stride), h_z_uniform(e_.z_uniform), h_z_pow2(e_.z_pow2), h_z0(e_.z0),
           h_zin(e_.zin),
@@ -1221,6 +1232,10 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                 waited = 0;
                 services++;
                 // =========================== SERVICE phase ===========================
+#ifdef PGR_DBG_REPLAY
+                const unsigned long long dbg_s0 = __builtin_amdgcn_s_memtime();
+                unsigned long long dbg_s1 = dbg_s0, dbg_s4 = dbg_s0, dbg_s5 = dbg_s0, dbg_r0 = dbg_s0, dbg_r3 = dbg_s0;
+#endif
                 if (pend && parked) {
                     parked = false;
                     const unsigned active = pk_active;
@@ -1230,6 +1245,9 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                     (void)n0; (void)c_new; (void)es0; (void)es1; (void)es2;
                     Dense D;
                     PGR_FORM_Q();
+#ifdef PGR_DBG_REPLAY
+                    dbg_s1 = __builtin_amdgcn_s_memtime();
+#endif
                     int ev = -1;
                     double best = 0;
                     // (a step that crosses the surface nearly always also crosses the bounding box's
@@ -1265,23 +1283,29 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                         if (pre) {
                             const double bslope = bottom ? (be - bs) : 0.0;  // per unit s
                             double lo = 0.0, hi = 1.0;
-                            double sN = Fa / (Fa - Fb);  // secant start
+                            double sN = fdiv(Fa, Fa - Fb);  // secant start
                             double dFs = 0;
-                            for (int it = 0; it < 12; it++) {
+                            // safeguarded Newton: four steps in a row (quadratic convergence from the secant
+                            // start: ~1e-3, 1e-6, 1e-12 of the step), more only for a lane that still moves
+                            for (int it = 0; it < 16; it++) {
                                 double zs = y1 + h * (sN * (q0 + sN * (q1 + sN * (q2 + sN * q3))));
                                 double dz = h * (q0 + sN * (2 * q1 + sN * (3 * q2 + sN * 4 * q3)));
                                 double F = zs, dF = dz;
-                                if (bottom) { F = zs - C.bathy(t + sN * h); dF = dz - bslope; }
+                                if (any_bottom) {
+                                    const double bq = C.bathy(t + sN * h);
+                                    F = bottom ? zs - bq : zs;
+                                    dF = bottom ? dz - bslope : dz;
+                                }
                                 dFs = dF;
                                 bool crossed = bottom ? (F > 0) : (F < 0);
                                 if (crossed) hi = sN; else lo = sN;
-                                double sn = sN - F / dF;
+                                double sn = sN - F * frcp_seed(dF);
                                 // (closed bracket: when F evaluates to exactly 0 the Newton step is
                                 // zero, sn == lo, and that is convergence, not an escape)
                                 if (!(sn >= lo && sn <= hi)) sn = 0.5 * (lo + hi);
                                 double ds = fabs(sn - sN);
                                 sN = sn;
-                                if (ds * h < 1e-12 * (1.0 + fabs(t))) break;
+                                if (it >= 3 && ballot64(ds * h >= 1e-12 * (1.0 + fabs(t))) == 0) break;
                             }
                             const double xs = t + sN * h;
                             // E: rounding noise of F as the event evaluates it.  z(x) = h (Q p) + y_old: half an ulp
@@ -1304,9 +1328,15 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
         const double e1_ = xx_, e2_ = e1_ * xx_, e3_ = e2_ * xx_, e4_ = e3_ * xx_;                               \
         const double z_ = D.h * (D.q[1][0] * e1_ + D.q[1][1] * e2_ + D.q[1][2] * e3_ + D.q[1][3] * e4_) + y1;   \
         const double pz_ = D.h * (D.q[2][0] * e1_ + D.q[2][1] * e2_ + D.q[2][2] * e3_ + D.q[2][3] * e4_) + y2;  \
-        double c_, cp_;                                                                                          \
-        C.lookup((X_), z_, c_, cp_);                                                                             \
-        const double pc_ = pz_ * c_;                                                                             \
+        /* theta = degrees(arcsin(p c)) only enters through its sign and through |p c| <= 1 (NaN otherwise,   \
+           Q7): with 0 < c <= c_hi (the table's maximum, a margin for the extrapolated sliver above the        \
+           surface included) |p| c_hi < 1 settles both from p alone -- no table look-up */                    \
+        double pc_ = pz_;                                                                                        \
+        if (ballot64(!((C.h_c_lo > 0) & (fabs(pz_) * C.h_c_hi < 1.0))) != 0) {                                    \
+            double c_, cp_;                                                                                      \
+            C.lookup((X_), z_, c_, cp_);                                                                         \
+            pc_ = pz_ * c_;                                                                                      \
+        }                                                                                                        \
         const double bd_ = any_bottom ? C.bathy(X_) : 0.0;                                                       \
         FIRED_ = bottom ? ((pc_ > 0) & (pc_ <= 1.0) & (z_ > bd_)) : ((z_ < 0) & (pc_ < 0) & (pc_ >= -1.0));       \
         BBOX_ = (z_ > C.h_zhi_tol) | (z_ < C.h_zlo_tol) | ((X_) < C.h_rlo_tol) | ((X_) > C.h_rhi_tol);           \
@@ -1403,7 +1433,8 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                         {
                             const unsigned long long dbg_t3 = __builtin_amdgcn_s_memtime();
                             const int ln = threadIdx.x & 63;
-                            fallbacks += (ln == 2) ? (int)(dbg_t1 - dbg_t0) : (ln == 3) ? (int)(dbg_t3 - dbg_t1) : (ln == 4) ? (int)dbg_ev : (ln == 5) ? dbg_it : (int)(dbg_t3 - dbg_t0);
+                            dbg_r0 = dbg_t0; dbg_r3 = dbg_t3;
+                            fallbacks += (ln == 2) ? (int)(dbg_t1 - dbg_t0) : (ln == 3) ? (int)(dbg_t3 - dbg_t1) : (ln == 4) ? (int)dbg_ev : (ln == 5) ? dbg_it : 0;
                         }
 #endif
                         if (live && done) { best = cur; ev = bottom ? 1 : 0; }
@@ -1442,6 +1473,9 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                             if (ev < 0 || xcur < best) { best = xcur; ev = k; }
                         }
                     }
+#ifdef PGR_DBG_REPLAY
+                    dbg_s4 = __builtin_amdgcn_s_memtime();
+#endif
                     if (status == RUNNING) {
                         const double t_end = best;
                         // samples of this (truncated) step, REF/launch_rays.py:763-772 (Q5)
@@ -1466,7 +1500,9 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                         else {
                             double c, cp;
                             C.lookup(t, y1, c, cp);
-                            double theta = pgr_cr_asin(y2 * c) * (180.0 / M_PI);  // ray_angle
+                            const double pc_b = y2 * c;
+                            const PGR_ASIN_DD_T A_b = PGR_ASIN_DD(pc_b);
+                            double theta = PGR_ASIN_DD_HI(A_b) * (180.0 / M_PI);  // ray_angle
                             double theta_b;
                             if (ev == 0) {
                                 theta_b = -theta;
@@ -1501,7 +1537,8 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                                 if ((a.flags & PGR_TERMINATE_BACKWARDS) && (fabs(theta_b) > 90))
                                     status = PGR_RAY_BACKWARD;
                                 else {
-                                    y2 = pgr_cr_sin(theta_b * (M_PI / 180.0)) / c;
+                                    // (theta_b = -theta at the surface and on a flat floor: the sine of minus an arcsine, cheaply)
+                                    y2 = fdiv(PGR_SIN_REFLECT(theta_b * (M_PI / 180.0), pc_b, A_b), c);
                                     need_init = true;
                                     if (!(t < t_bound)) status = PGR_RAY_OK;
                                     else if (n_steps > a.max_steps) status = PGR_RAY_MAX_STEPS;
@@ -1510,6 +1547,9 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                         }
                     }
                 }
+#ifdef PGR_DBG_REPLAY
+                dbg_s5 = __builtin_amdgcn_s_memtime();
+#endif
                 if (status == RUNNING && need_init) {
                     // ---- fresh solve_ivp: RK45.__init__ (SCIPY/rk.py:84-104) ----
                     double c;
@@ -1518,19 +1558,20 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                     double interval = fabs(t_bound - t);
                     double s0 = atol + fabs(y0) * rtol, s1 = atol + fabs(y1) * rtol,
                            s2 = atol + fabs(y2) * rtol;
-                    double d0 = rms3(y0 / s0, y1 / s1, y2 / s2);
-                    double d1 = rms3(f0 / s0, f1 / s1, f2 / s2);
-                    double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+                    // (fdiv: correctly rounded like the compiler's division, a third of its instructions)
+                    double d0 = rms3(fdiv(y0, s0), fdiv(y1, s1), fdiv(y2, s2));
+                    double d1 = rms3(fdiv(f0, s0), fdiv(f1, s1), fdiv(f2, s2));
+                    double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : fdiv(0.01 * d0, d1);
                     if (!(h0 < interval)) h0 = interval;
                     double e0, e1, e2, cdummy;
                     C.rhs(t + h0 * 1.0, y1 + h0 * 1.0 * f1, y2 + h0 * 1.0 * f2, e0, e1, e2, cdummy);
-                    double d2 = rms3((e0 - f0) / s0, (e1 - f1) / s1, (e2 - f2) / s2) / h0;
+                    double d2 = fdiv(rms3(fdiv(e0 - f0, s0), fdiv(e1 - f1, s1), fdiv(e2 - f2, s2)), h0);
                     double h1;
                     if (d1 <= 1e-15 && d2 <= 1e-15) {
                         h1 = h0 * 1e-3;
                         if (!(h1 > 1e-6)) h1 = 1e-6;
                     } else {
-                        h1 = pgr_cr_pow_p02(0.01 / ((d2 > d1) ? d2 : d1));
+                        h1 = pgr_cr_pow_p02(fdiv(0.01, (d2 > d1) ? d2 : d1));
                     }
                     h_abs = 100 * h0;
                     if (h1 < h_abs) h_abs = h1;
@@ -1544,6 +1585,15 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                         rnext = G.at(jnext);
                     }
                 }
+#ifdef PGR_DBG_REPLAY
+                {
+                    const unsigned long long dbg_s6 = __builtin_amdgcn_s_memtime();
+                    const int ln = threadIdx.x & 63;
+                    // lanes 6..11: whole service; stage replay + Q; Newton + band edges; (replay: lanes 2-4); samples + root + reflection; init
+                    fallbacks += (ln == 6) ? (int)(dbg_s6 - dbg_s0) : (ln == 7) ? (int)(dbg_s1 - dbg_s0) : (ln == 8) ? (int)(dbg_r0 - dbg_s1)
+                               : (ln == 9) ? (int)(dbg_s4 - dbg_r3) : (ln == 10) ? (int)(dbg_s5 - dbg_s4) : (ln == 11) ? (int)(dbg_s6 - dbg_s5) : 0;
+                }
+#endif
             }
         }
     } while (ballot64(status == RUNNING) != 0);
@@ -2038,6 +2088,13 @@ extern "C" int pgr_env_create(pgr_env** out, int device, const double* cin, cons
     d.beta_zero = 1;
     for (double v : pp) if (v != 0.0) d.beta_zero = 0;
     d.inv_db = d.b_uniform ? 1.0 / d.db : 0.0;
+    d.c_lo = cin[0]; d.c_hi = cin[0];
+    for (int64_t k = 0; k < nr * nz; k++) {
+        d.c_lo = cin[k] < d.c_lo ? cin[k] : d.c_lo;
+        d.c_hi = cin[k] > d.c_hi ? cin[k] : d.c_hi;
+    }
+    if (!(d.c_lo > 0) || !std::isfinite(d.c_hi)) { d.c_lo = 0.0; d.c_hi = INFINITY; }  // no shortcut for such a table
+    d.c_hi *= 1.001;
     const double tol = 1e-6;
     d.zhi_tol = zin[nz - 1] + tol;
     d.zlo_tol = zin[0] - tol;

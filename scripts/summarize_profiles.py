@@ -29,11 +29,15 @@ for key, pre in (("sample", ""), ("sample-nosave", "nosave_")):
     # MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KB; gfx950 FETCH_SIZE counts half the bytes
     out[key] = {"rays": 100000, "FETCH_SIZE_KB": fe, "WRITE_SIZE_KB": wr,
                 "hbm_gb_per_launch": (2 * fe + wr) * 1024 / 1e9,
+                "note": f"profiles/{rnd}_traffic.json: rocprofv3 PMC passes of this command (FETCH_SIZE x 2 per the gfx950 "
+                        "correction + WRITE_SIZE, fan kernel, last dispatch)",
                 "command": f"rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- "
-                           f"python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline{' --no-save' if pre else ''}"}
+                           f"python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-eigenray{' --no-save' if pre else ''}"}
 sq = fan_counters(f"{tag}_sq")
 if sq:
     out["sq_counters_sample"] = sq
+    if "sample" in out and "SQ_INSTS_VALU" in sq:
+        out["sample"]["valu_wave_instructions_per_launch"] = sq["SQ_INSTS_VALU"]
 old = os.path.join(ROOT, "profiles", f"{rnd}_traffic.json")
 if os.path.exists(old):
     prev = json.load(open(old))
