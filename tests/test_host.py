@@ -315,19 +315,27 @@ def test_committed_bench_line_and_profiles_are_well_formed():
     """profiles/ carries the round's rocprofv3 summaries and the bench line they belong to."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    d = json.load(open(os.path.join(root, "profiles", "r01_bench_line.json")))
+    d = json.load(open(os.path.join(root, "profiles", "r02_bench_line.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
-              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "roofline_valu", "cpu_baseline",
+              "cpu_baseline_c", "eigenray", "build"):
         assert k in d, k
     assert d["dtype"] == "f64" and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert "workload" in d["config"] and "model" not in d["config"]
     rf = d["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert rf["traffic"] is not None and 0 < d["roofline_valu"]["frac"] < 1
     assert d["cpu_baseline"]["kind"] in ("port", "reference") and d["cpu_baseline"]["cores"] >= 1
-    stats = open(os.path.join(root, "profiles", "r01_kernel_stats.csv")).read()
+    assert "solve_ivp" in d["cpu_baseline"]["sample"] and d["build"].startswith("layout: relaid")
+    for k in ("wall_s", "fan_s", "search_s", "brackets", "found", "failed", "launches"):
+        assert k in d["eigenray"], k
+    stats = open(os.path.join(root, "profiles", "r02_kernel_stats.csv")).read()
     assert "pgr_fan_kernel" in stats
-    tr = json.load(open(os.path.join(root, "profiles", "r01_traffic.json")))
-    assert tr["sample"]["hbm_gb_per_launch"] > 0
+    tr = json.load(open(os.path.join(root, "profiles", "r02_traffic.json")))
+    assert tr["sample"]["hbm_gb_per_launch"] > 0 and tr["sample"]["valu_wave_instructions_per_launch"] > 1e9
+    c2 = json.load(open(os.path.join(root, "profiles", "r02_config2_counters.json")))
+    assert 0.9 < c2["end_state_only"]["l2_hit_rate"] <= 1 and "pgr_fan_kernel<false" in open(
+        os.path.join(root, "profiles", "r02_config2_kernel_stats.csv")).read()
 
 
 # ----------------------------------------------------------------------------- build: instruction layout
