@@ -192,7 +192,8 @@ def eigenray_leg(env_obj, n_rays):
                "failed": len(er.failed_eray_theta_brackets[0]),
                "launches": int(er_mod.LAST_SEARCH_STATS.get("launches", 0)),
                "config": "configs[3]: Munk dz=1 m, source (0, 1000 m), receiver (1000 km, 1000 m), "
-                         "ztol 1 m, max_iter 20; through pr.shoot_rays + pr.find_eigenrays, host buffers included"}
+                         "ztol 1 m, max_iter 20; through pr.shoot_rays + pr.find_eigenrays (device-resident "
+                         "false-position loop, pgr_eigen_refine), host buffers included"}
     return out
 
 

@@ -40,6 +40,7 @@ extern "C" {
 #define PGR_RAY_MAX_STEPS 5      /* guard: max_steps accepted steps exceeded (no reference counterpart) */
 #define PGR_RAY_BETA_RANGE 6     /* bottom-angle interp1d out of bounds (ValueError) REF/launch_rays.py:469 */
 #define PGR_RAY_EVENT_ERROR 7    /* event root not bracketed (brentq ValueError) */
+#define PGR_RAY_SKIPPED 8        /* not integrated: PGR_SKIP_NAN_Y0 and a NaN initial slowness (a finished eigenray bracket) */
 
 /* flags for pgr_shoot_fan* */
 #define PGR_TERMINATE_BACKWARDS 1u /* REF/launch_rays.py:19,474 (default True) */
@@ -74,6 +75,9 @@ extern "C" {
                                       n_surf, status and a valid mark (1) as four int32 in the last two
                                       slots -- the end record the multi-GPU all-gather ships, written by
                                       the kernel instead of packed afterwards */
+
+#define PGR_SKIP_NAN_Y0 512u       /* rays whose y0[k][2] is NaN are not integrated (status PGR_RAY_SKIPPED): the
+                                      eigenray refinement parks its finished brackets this way */
 
 typedef struct pgr_env pgr_env; /* opaque: environment tables resident in HBM */
 
@@ -122,6 +126,28 @@ int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, double sourc
                          double atol, uint32_t flags, int64_t max_steps, double* T, double* z,
                          double* p, double* end_state, int32_t* n_bott, int32_t* n_surf,
                          int32_t* status, int32_t* n_steps, int32_t* n_rej, void* stream);
+
+/* Eigenray refinement: pygenray's _find_single_eigenray (REF/eigenrays.py:206-268) for nbk brackets at
+ * once, the whole false-position loop on the device.  Per bracket k the fan rays th1[k], th2[k] (user
+ * launch angles, degrees) ended at stored-convention depths z1[k], z2[k] on either side of
+ * -receiver_depth.  Each iteration is: trial angle (REF/eigenrays.py:118-120, 261-263) and its initial
+ * state y0 = [0, source_depth, sin(radians(-theta)) / c_source] (REF/launch_rays.py:251,284-285; the
+ * sine correctly rounded) in one small kernel, ONE fan launch (end state only) over all brackets still
+ * active (the others are skipped in place, PGR_SKIP_NAN_Y0), the update of the reference's loop in the
+ * next small kernel: dropped ray -> failed; |z_end + receiver_depth| < ztol -> found; else the trial ray
+ * replaces the bracket end on its side; give up after max_iter + 2 trial rays (REF/eigenrays.py:265-268).
+ * Everything is enqueued on the environment's stream; the host only reads back the count of active
+ * brackets after each iteration.  HOST arrays in and out:
+ *   theta[k]  the eigenray's launch angle (user convention) or NaN;   state[k]  1 found, 2 trial ray
+ *   dropped (the reference prints "Failed to find eigen ray" and gives up), 3 iteration limit;
+ *   n_trial[k] trial rays shot;  z_end[k], t_end[k] stored-convention end depth / arrival time of the
+ *   last trial ray.  *launches = fan launches made.  c_source = c at the source (the caller's
+ *   bilinear_interp, REF/launch_rays.py:284). */
+int pgr_eigen_refine(pgr_env* env, int64_t nbk, const double* th1, const double* th2, const double* z1,
+                     const double* z2, double receiver_depth, double source_depth, double source_range,
+                     double receiver_range, double c_source, double rtol, double atol, uint32_t flags,
+                     int64_t max_steps, double ztol, int32_t max_iter, double* theta, int32_t* state,
+                     int32_t* n_trial, double* z_end, double* t_end, int32_t* launches);
 
 /* Arrival-time histogram of a fan's surviving rays on the device (BASELINE configs[4]; the
  * reduction behind pygenray's time-front scatter RayFan.plot_time_front, REF/ray_objects.py:157-222;

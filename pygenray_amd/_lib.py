@@ -37,9 +37,10 @@ PGR_STORED_SIGN = 64
 PGR_COMPACT = 128
 PGR_PACKED_END = 256
 PGR_SAVE_LINSPACE = 8
+PGR_SKIP_NAN_Y0 = 512
 
 RAY_STATUS = {0: "ok", 1: "vertical", 2: "bbox", 3: "backward", 4: "step_too_small",
-              5: "max_steps", 6: "bottom_angle_range", 7: "event_error"}
+              5: "max_steps", 6: "bottom_angle_range", 7: "event_error", 8: "skipped"}
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _ip = ctypes.POINTER(ctypes.c_int32)
@@ -337,6 +338,25 @@ class EnvHandle:
         L.pgr_debug_step.argtypes = [_vp, _dp, _dp, _dp, _i64, ctypes.c_double, ctypes.c_double, _dp]
         check(L.pgr_debug_step(self._h, _p(t), _p(y), _p(h), len(t), float(rtol), float(atol), _p(out)))
         return out
+
+    def eigen_refine(self, th1, th2, z1, z2, receiver_depth, source_depth, source_range, receiver_range, c_source,
+                     rtol=1e-9, atol=1e-6, terminate_backwards=True, max_steps=1_000_000, ztol=1.0, max_iter=20):
+        """pgr_eigen_refine: the false-position loop of REF/eigenrays.py:206-268 for all brackets, on the device."""
+        L = load()
+        th1, th2, z1, z2 = (_c(a).reshape(-1) for a in (th1, th2, z1, z2))
+        n = len(th1)
+        theta = np.full(n, np.nan); zend = np.full(n, np.nan); tend = np.full(n, np.nan)
+        state = np.zeros(n, np.int32); ntrial = np.zeros(n, np.int32)
+        launches = ctypes.c_int32(0)
+        L.pgr_eigen_refine.restype = ctypes.c_int
+        L.pgr_eigen_refine.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp] + [ctypes.c_double] * 7 + [ctypes.c_uint32, _i64,
+                                       ctypes.c_double, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_int32)]
+        check(L.pgr_eigen_refine(self._h, n, _vptr(th1), _vptr(th2), _vptr(z1), _vptr(z2), float(receiver_depth),
+                                 float(source_depth), float(source_range), float(receiver_range), float(c_source),
+                                 float(rtol), float(atol), PGR_TERMINATE_BACKWARDS if terminate_backwards else 0,
+                                 int(max_steps), float(ztol), int(max_iter), _vptr(theta), _vptr(state), _vptr(ntrial),
+                                 _vptr(zend), _vptr(tend), ctypes.byref(launches)))
+        return dict(theta=theta, state=state, n_trial=ntrial, z_end=zend, t_end=tend, launches=int(launches.value))
 
     def eval_points(self, x, y):
         x = _c(x); y = _c(y).reshape(-1, 3)

@@ -986,6 +986,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     double f0 = 0, f1 = 0, f2 = 0, h_abs = 0;
     unsigned g = 0;
     int status = valid ? RUNNING : PGR_RAY_OK;
+    if (valid && (a.flags & PGR_SKIP_NAN_Y0) && (y2 != y2)) status = PGR_RAY_SKIPPED;  // a parked eigenray bracket
     bool need_init = true, rejected = false, parked = false;
     int nb = 0, ns = 0, n_steps = 0, n_rej = 0;
     int jnext = 0;
@@ -2489,6 +2490,133 @@ extern "C" int pgr_shoot_fan(pgr_env* env, const double* y0, int64_t N, double s
     if (n_steps) HIPCHK(hipMemcpyAsync(n_steps, dn1.p, N * 4, hipMemcpyDeviceToHost, st));
     if (n_rej) HIPCHK(hipMemcpyAsync(n_rej, dn2.p, N * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// Eigenray refinement on the device: pygenray's _find_single_eigenray (REF/eigenrays.py:206-268) for all
+// brackets at once.  One launch of pgr_eigen_step per iteration applies the reference's loop body to the
+// result of the previous trial fan and writes the next trial rays' initial states; the fan kernel runs
+// between two of them (finished brackets carry a NaN y0 and are skipped, PGR_SKIP_NAN_Y0).
+// ------------------------------------------------------------------------------------
+struct EigenState {
+    double* th1; double* th2; double* z1; double* z2;   // bracket ends (user angle, stored-convention depth)
+    double* theta;       // current trial angle; the found angle at the end
+    double* y0;          // [nbk][3] initial states of the trial rays
+    const double* end;   // [nbk][3] end states of the last trial fan (ODE convention)
+    const int32_t* status;
+    int32_t* state;      // 0 active, 1 found, 2 trial ray dropped, 3 iteration limit
+    int32_t* n_trial;
+    double* z_end; double* t_end;
+    int32_t* n_active;   // [1] brackets still active after this step
+};
+
+__global__ void pgr_eigen_step(EigenState e, int64_t nbk, int first, int iter_count, int max_iter, double rd,
+                               double ztol, double source_depth, double c_source)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nbk) return;
+    int st = e.state[k];
+    double th = e.theta[k];
+    if (first) {
+        // REF/eigenrays.py:118-120
+        th = e.th1[k] - (e.z1[k] + rd) * (e.th2[k] - e.th1[k]) / (e.z2[k] - e.z1[k]);
+    } else if (st == 0) {
+        const double zr = -e.end[3 * k + 1];  // ray.z[-1], stored convention (REF/ray_objects.py:51)
+        e.z_end[k] = zr;
+        e.t_end[k] = e.end[3 * k + 0];
+        if (e.status[k] != PGR_RAY_OK) {
+            st = 2;                                                  // REF/eigenrays.py:241-245
+        } else if (fabs(zr + rd) < ztol) {
+            st = 1;                                                  // :247-250
+        } else {
+            const double s1 = e.z1[k] + rd, sr = zr + rd;
+            // np.sign(ray.z[-1] + rd) == np.sign(z1 + rd)            :253-259
+            const bool same = ((sr > 0) - (sr < 0)) == ((s1 > 0) - (s1 < 0));
+            if (same) { e.z1[k] = zr; e.th1[k] = th; } else { e.z2[k] = zr; e.th2[k] = th; }
+            th = e.th1[k] - (e.z1[k] + rd) * (e.th2[k] - e.th1[k]) / (e.z2[k] - e.z1[k]);   // :261-263
+            if (iter_count > max_iter) st = 3;                       // :265-268 (checked with the count BEFORE its increment)
+        }
+        e.state[k] = st;
+    }
+    e.theta[k] = th;
+    const double nan = __longlong_as_double(0x7ff8000000000000LL);
+    if (st == 0) {
+        // shoot_ray(theta): ODE angle = -theta (REF/launch_rays.py:251), y0 = [0, z_s, sin(radians(.)) / c] (:284-285)
+        e.y0[3 * k + 0] = 0.0;
+        e.y0[3 * k + 1] = source_depth;
+        e.y0[3 * k + 2] = pgr_cr_sin((-th) * (M_PI / 180.0)) / c_source;
+        e.n_trial[k] += 1;
+        atomicAdd(e.n_active, 1);
+    } else {
+        e.y0[3 * k + 0] = 0.0; e.y0[3 * k + 1] = source_depth; e.y0[3 * k + 2] = nan;
+    }
+}
+
+extern "C" int pgr_eigen_refine(pgr_env* env, int64_t nbk, const double* th1, const double* th2, const double* z1,
+                                const double* z2, double receiver_depth, double source_depth, double source_range,
+                                double receiver_range, double c_source, double rtol, double atol, uint32_t flags,
+                                int64_t max_steps, double ztol, int32_t max_iter, double* theta, int32_t* state,
+                                int32_t* n_trial, double* z_end, double* t_end, int32_t* launches)
+{
+    if (!env) return fail("pgr_eigen_refine: null env");
+    if (nbk < 0) return fail("pgr_eigen_refine: negative bracket count");
+    if (launches) *launches = 0;
+    if (nbk == 0) return 0;
+    if (!th1 || !th2 || !z1 || !z2 || !theta || !state || !n_trial || !z_end || !t_end)
+        return fail("pgr_eigen_refine: null argument");
+    if (!(c_source > 0) || !(ztol > 0) || max_iter < 0) return fail("pgr_eigen_refine: bad argument");
+    HIPCHK(hipSetDevice(env->device));
+    std::lock_guard<std::mutex> lock(env->ws_mutex);
+    if (!env->stream) HIPCHK(hipStreamCreateWithFlags(&env->stream, hipStreamNonBlocking));
+    hipStream_t st = env->stream;
+    // one device block: 4 bracket arrays, theta, z_end, t_end (doubles), y0[3], end[3], 5 int arrays, the counter
+    const size_t nd = (size_t)nbk;
+    const size_t bytes = nd * 8 * (7 + 3 + 3) + nd * 4 * 6 + 256;
+    DevBuf buf;
+    if (buf.alloc(bytes)) return fail("pgr_eigen_refine: device allocation failed");
+    double* d = (double*)buf.p;
+    EigenState e{};
+    e.th1 = d; e.th2 = d + nd; e.z1 = d + 2 * nd; e.z2 = d + 3 * nd; e.theta = d + 4 * nd;
+    e.z_end = d + 5 * nd; e.t_end = d + 6 * nd; e.y0 = d + 7 * nd;
+    double* end = d + 10 * nd;
+    e.end = end;
+    int32_t* ib = (int32_t*)(d + 13 * nd);
+    int32_t* status = ib; e.status = status;
+    e.state = ib + nd; e.n_trial = ib + 2 * nd;
+    int32_t* nbott = ib + 3 * nd; int32_t* nsurf = ib + 4 * nd;
+    e.n_active = ib + 5 * nd;
+    HIPCHK(hipMemsetAsync(buf.p, 0, bytes, st));
+    HIPCHK(hipMemcpyAsync(e.th1, th1, nd * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(e.th2, th2, nd * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(e.z1, z1, nd * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(e.z2, z2, nd * 8, hipMemcpyHostToDevice, st));
+    const dim3 grid((unsigned)((nbk + 127) / 128)), block(128);
+    int n_launch = 0;
+    for (int it = 0;; it++) {
+        // iter_count of the reference when it tests the limit after trial ray number `it`: it - 1
+        HIPCHK(hipMemsetAsync(e.n_active, 0, 4, st));
+        hipLaunchKernelGGL(pgr_eigen_step, grid, block, 0, st, e, nbk, it == 0 ? 1 : 0, it - 1, (int)max_iter, receiver_depth,
+                           ztol, source_depth, c_source);
+        HIPCHK(hipGetLastError());
+        int32_t active = 0;
+        HIPCHK(hipMemcpyAsync(&active, e.n_active, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (active == 0) break;
+        if (it > max_iter + 2) return fail("pgr_eigen_refine: iteration guard");
+        int rc = pgr_shoot_fan_device(env, e.y0, nbk, source_range, receiver_range, nullptr, 1, rtol, atol,
+                                      (flags & PGR_TERMINATE_BACKWARDS) | PGR_SKIP_NAN_Y0, max_steps, nullptr, nullptr, nullptr,
+                                      end, nbott, nsurf, status, nullptr, nullptr, (void*)st);
+        if (rc) return rc;
+        n_launch++;
+    }
+    HIPCHK(hipMemcpyAsync(theta, e.theta, nd * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(z_end, e.z_end, nd * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(t_end, e.t_end, nd * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(state, e.state, nd * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(n_trial, e.n_trial, nd * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (launches) *launches = n_launch;
     return 0;
 }
 

@@ -18,59 +18,47 @@ LAST_SEARCH_STATS = {}
 
 def _regula_falsi_batch(z1, z2, th1, th2, receiver_depth, source_depth, source_range,
                         receiver_range, num_range_save, environment, ztol, max_iter, kwargs):
-    """Vectorised _find_single_eigenray (REF/eigenrays.py:206-268) for all brackets at once.
-    Returns (found mask, RayFan pieces of the found rays in stored convention)."""
+    """_find_single_eigenray (REF/eigenrays.py:206-268) for all brackets at once.  The whole
+    false-position loop runs on the device (pgr_eigen_refine: per iteration one small kernel for the
+    reference's loop body + the trial rays' initial states, one fan launch over the brackets still
+    active); the eigenrays found are then shot once more with trajectories.
+    Returns (found mask, launch angles, r, T, Z, P (stored convention), n_bott, n_surf)."""
+    from .launch_rays import _device_env
+    from .host_physics import bilinear_interp
     rtol = kwargs.get("rtol", 1e-9)
     terminate_backwards = kwargs.get("terminate_backwards", True)
     flatearth = kwargs.get("flatearth", True)
     device = kwargs.get("device", 0)
     quiet = kwargs.get("quiet", False)   # (not a reference kwarg: suppresses the per-bracket failure message)
     nbk = len(z1)
-    z1, z2, th1, th2 = (np.array(a, dtype=float) for a in (z1, z2, th1, th2))
-    theta = th1 - (z1 + receiver_depth) * (th2 - th1) / (z2 - z1)  # REF/eigenrays.py:118-120
-    active = np.ones(nbk, bool)
-    found = np.zeros(nbk, bool)
     S = int(num_range_save)
-    T = np.zeros((nbk, S)); Z = np.zeros((nbk, S)); P = np.zeros((nbk, S))
-    nb = np.zeros(nbk, np.int64); ns = np.zeros(nbk, np.int64)
-    th_found = np.zeros(nbk)
-    r = None
-    iter_count = 0
-    while active.any():
-        idx = np.where(active)[0]
-        # shoot_ray(theta): ODE angle = -theta (REF/launch_rays.py:251)
-        out = _shoot_ode_angles(source_depth, source_range, -theta[idx], receiver_range, S,
-                                environment, rtol, terminate_backwards, flatearth, device=device)
-        LAST_SEARCH_STATS["launches"] = LAST_SEARCH_STATS.get("launches", 0) + 1
-        LAST_SEARCH_STATS["trial_rays"] = LAST_SEARCH_STATS.get("trial_rays", 0) + len(idx)
-        r = out["r"]
-        dropped = out["status"] != 0
-        zend = -out["z"][:, -1]  # stored convention ray.z[-1]
-        for q in ([] if quiet else idx[dropped]):
+    backwards = receiver_range < source_range
+    env, (cin, rin, zin) = _device_env(environment, flatearth, backwards, device)
+    x0, x1 = (-source_range, -receiver_range) if backwards else (source_range, receiver_range)
+    c0 = bilinear_interp(x0, source_depth, rin, zin, cin)            # REF/launch_rays.py:284
+    out = env.eigen_refine(th1, th2, z1, z2, receiver_depth, source_depth, x0, x1, c0, rtol=rtol,
+                           terminate_backwards=terminate_backwards, ztol=ztol, max_iter=max_iter)
+    LAST_SEARCH_STATS["launches"] = LAST_SEARCH_STATS.get("launches", 0) + out["launches"]
+    LAST_SEARCH_STATS["trial_rays"] = LAST_SEARCH_STATS.get("trial_rays", 0) + int(out["n_trial"].sum())
+    if not quiet:
+        for q in np.where(out["state"] == 2)[0]:
             # REF/eigenrays.py:241-245
             print(f"Failed to find eigen ray for receiver depth {receiver_depth} [m] and "
-                  f"approximate launch angle {theta[q]} [m] ray θ = 90°")
-        active[idx[dropped]] = False
-        hit = (~dropped) & (np.abs(zend + receiver_depth) < ztol)
-        hq = idx[hit]
-        T[hq], Z[hq], P[hq] = out["T"][hit], -out["z"][hit], -out["p"][hit]
-        nb[hq], ns[hq] = out["n_bott"][hit], out["n_surf"][hit]
-        th_found[hq] = theta[hq]  # launch_angle flipped back (REF/eigenrays.py:249)
-        found[hq] = True
-        active[hq] = False
-        go = (~dropped) & (~hit)
-        gq = idx[go]
-        zg = zend[go]
-        same = np.sign(zg + receiver_depth) == np.sign(z1[gq] + receiver_depth)
-        z1[gq[same]] = zg[same]
-        th1[gq[same]] = theta[gq[same]]
-        z2[gq[~same]] = zg[~same]
-        th2[gq[~same]] = theta[gq[~same]]
-        with np.errstate(divide="ignore", invalid="ignore"):
-            theta[gq] = th1[gq] - (z1[gq] + receiver_depth) * (th2[gq] - th1[gq]) / (z2[gq] - z1[gq])
-        if iter_count > max_iter:  # REF/eigenrays.py:265-268
-            active[gq] = False
-        iter_count += 1
+                  f"approximate launch angle {out['theta'][q]} [m] ray θ = 90°")
+    found = out["state"] == 1
+    th_found = np.where(found, out["theta"], 0.0)
+    T = np.zeros((nbk, S)); Z = np.zeros((nbk, S)); P = np.zeros((nbk, S))
+    nb = np.zeros(nbk, np.int64); ns = np.zeros(nbk, np.int64)
+    r = np.linspace(source_range, receiver_range, S)
+    if found.any():
+        idx = np.where(found)[0]
+        # the eigenrays themselves, with trajectories: shoot_ray(theta), ODE angle = -theta (REF/launch_rays.py:251)
+        fin = _shoot_ode_angles(source_depth, source_range, -th_found[idx], receiver_range, S, environment, rtol,
+                                terminate_backwards, flatearth, device=device)
+        LAST_SEARCH_STATS["launches"] += 1
+        r = fin["r"]
+        T[idx], Z[idx], P[idx] = fin["T"], -fin["z"], -fin["p"]
+        nb[idx], ns[idx] = fin["n_bott"], fin["n_surf"]
     return found, th_found, r, T, Z, P, nb, ns
 
 

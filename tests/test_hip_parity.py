@@ -836,3 +836,67 @@ def test_config4_end_records_and_arrival_time_histogram_of_1e6_rays(lib):
     assert np.array_equal(okk, st[sub] == 0)
     assert np.mean(T[sub][okk] == o["T"][okk, -1]) >= 0.995
     env.close()
+
+
+def test_eigen_refine_device_loop_follows_the_reference_loop(lib):
+    """pgr_eigen_refine runs pygenray's _find_single_eigenray (REF/eigenrays.py:206-268) for all brackets
+    on the device.  The checker is the same loop written out in NumPy around host-launched fans (one
+    fan per iteration): same outcome per bracket (found / trial ray dropped / iteration limit), same
+    number of trial rays, the same trial angles to 1e-10 degrees (the device computes sin(radians(.)) of
+    the initial slowness correctly rounded, NumPy with the platform libm: one ulp apart now and then).
+    Coarse fans so that the false position takes several steps, and a fan across bounce-count
+    discontinuities (false brackets that run into the iteration limit)."""
+    from pygenray_amd.host_physics import bilinear_interp
+    arrs = munk_arrays(200e3)
+    env = lib.EnvHandle(*arrs)
+    zs, rd, x1 = 1000.0, 1200.0, 200e3
+    c0 = bilinear_interp(0.0, zs, arrs[2], arrs[3], arrs[0])
+
+    def shoot(theta_user):
+        y0 = np.stack([np.zeros(len(theta_user)), np.full(len(theta_user), zs), np.sin(np.radians(-theta_user)) / c0], 1)
+        o = env.shoot_fan(y0, 0.0, x1, 2, save=False)
+        return o["status"], -o["end"][:, 1]
+
+    for grid in (np.linspace(-12, 12, 25), np.linspace(-19.5, 19.5, 40)):
+        st, zend = shoot(grid)
+        ok = st == 0
+        th, ze = grid[ok], zend[ok]
+        starts = np.where(np.diff(np.sign(ze + rd)))[0]
+        assert len(starts) >= 3
+        th1, th2, z1, z2 = th[starts].copy(), th[starts + 1].copy(), ze[starts].copy(), ze[starts + 1].copy()
+        got = env.eigen_refine(th1, th2, z1, z2, rd, zs, 0.0, x1, c0, ztol=1.0, max_iter=20)
+        # the reference's loop, bracket by bracket in lock step
+        n = len(starts)
+        state = np.zeros(n, int); ntrial = np.zeros(n, int)
+        theta = th1 - (z1 + rd) * (th2 - th1) / (z2 - z1)
+        it = 0
+        while (state == 0).any():
+            a = np.where(state == 0)[0]
+            s_, z_ = shoot(theta[a])
+            ntrial[a] += 1
+            for q, k in enumerate(a):
+                if s_[q] != 0:
+                    state[k] = 2
+                elif abs(z_[q] + rd) < 1.0:
+                    state[k] = 1
+                else:
+                    if np.sign(z_[q] + rd) == np.sign(z1[k] + rd):
+                        z1[k], th1[k] = z_[q], theta[k]
+                    else:
+                        z2[k], th2[k] = z_[q], theta[k]
+                    theta[k] = th1[k] - (z1[k] + rd) * (th2[k] - th1[k]) / (z2[k] - z1[k])
+                    if it > 20:
+                        state[k] = 3
+            it += 1
+        assert np.array_equal(got["state"], state) and np.array_equal(got["n_trial"], ntrial)
+        assert (state == 1).sum() >= 2
+        np.testing.assert_allclose(got["theta"][state == 1], theta[state == 1], rtol=0, atol=1e-10)
+        assert np.all(np.abs(got["z_end"][state == 1] + rd) < 1.0)
+        assert got["launches"] == ntrial.max()
+    assert ntrial.max() >= 4
+    # nothing to do / bad arguments
+    e = env.eigen_refine(np.zeros(0), np.zeros(0), np.zeros(0), np.zeros(0), rd, zs, 0.0, x1, c0)
+    assert e["launches"] == 0 and e["state"].shape == (0,)
+    with pytest.raises(lib.PgrError):
+        env.eigen_refine(th1, th2, z1, z2, rd, zs, 0.0, x1, -1.0)
+    env.close()
