@@ -1,0 +1,42 @@
+"""Randomised BIT-PARITY sweep, GPU vs the oracle in its correctly-rounded-libm mode, over the random
+environments and shots of tests/helpers.random_case.  Every ray must agree bit for bit -- status,
+bounce counts, accepted and rejected steps, end state, every sample (SciPy order) -- except the
+documented 1/sqrt(1 - 2^-53) class (at most 1 in 1000).
+usage: fuzz_bitparity.py [n_envs] [lib.so]"""
+import sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import oracle
+from helpers import y0_for, random_case
+from pygenray_amd import _lib
+
+n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+if len(sys.argv) > 2:
+    _lib.LIB_PATH = os.path.abspath(sys.argv[2])
+tot = odd = 0
+worst = []
+t_start = time.time()
+for seed in range(n_seeds):
+    arrs, (src, x0, th), kw, desc = random_case(seed)
+    y0 = y0_for(oracle, arrs, src, x0, th)
+    env = _lib.EnvHandle(*arrs)
+    g = env.shoot_fan(y0, kw["x0"], kw["x1"], kw["S"], rtol=kw["rtol"], exact_samples=True, terminate_backwards=kw["terminate_backwards"])
+    env.close()
+    o = oracle.shoot_fan(*arrs, y0, kw["x0"], kw["x1"], kw["S"], rtol=kw["rtol"], math=oracle.MATH_CR,
+                         terminate_backwards=kw["terminate_backwards"])
+    ok = o["status"] == 0
+    same = (g["status"] == o["status"])
+    same &= ~ok | ((g["n_bott"] == o["n_bott"]) & (g["n_surf"] == o["n_surf"]) & (g["n_steps"] == o["n_steps"]) & (g["n_rej"] == o["n_rej"]))
+    for nm in "Tzp":
+        same &= np.all((g[nm] == o[nm]) | (np.isnan(g[nm]) & np.isnan(o[nm])), axis=1)
+    end_ref = np.stack([o["T"][:, -1], o["z"][:, -1], o["p"][:, -1]], 1)
+    same &= ~ok | np.all(g["end"] == end_ref, axis=1)
+    n_odd = int((~same).sum())
+    tot += len(th); odd += n_odd
+    bounces = int((o["n_bott"] + o["n_surf"])[ok].sum())
+    print(f"seed {seed:3d}: {desc} dropped {int((~ok).sum()):3d} bounces {bounces:5d}  not bit-identical: {n_odd}"
+          + (f"  <-- rays {np.where(~same)[0][:6]} status g/o {g['status'][~same][:4]}/{o['status'][~same][:4]}" if n_odd else ""), flush=True)
+    if n_odd:
+        worst.append((seed, n_odd))
+print(f"{n_seeds} environments, {tot} rays, {odd} not bit-identical ({odd / tot:.2e}); {time.time() - t_start:.0f} s; seeds with odd rays: {worst}")

@@ -180,3 +180,50 @@ def assert_fan_parity(test, ref, noise_runs=None, scales=None, label="", abs_flo
                 assert med <= floor, f"{label}: median {nm} deviation of {name} rays {med:.3e} > {floor:.3e}"
                 worst[nm + "_median_" + name] = med / scale
     return worst
+
+
+def random_case(seed, n_rays=128):
+    """A random smooth environment + shot for the bit-parity sweep (scripts/fuzz_bitparity.py and
+    tests/test_hip_parity.py): uniform / power-of-two / stretched depth grids, uniform / random range
+    grids starting anywhere (also negative), flat / sloping floors, range (in)dependent sound speed,
+    forward frames and the mirrored frame of a backwards shot, random source range, tolerance, save grid.
+    Returns (arrs, y0_args, shot kwargs, description)."""
+    rng = np.random.default_rng(5000 + seed)
+    zmax = rng.uniform(1500, 6000)
+    nz = int(rng.integers(150, 2500))
+    kind_z = int(rng.integers(0, 3))
+    if kind_z == 0:
+        z = np.linspace(0, zmax, nz)
+    elif kind_z == 1:
+        z = np.arange(0, zmax, 2.0 ** rng.integers(-1, 3))
+    else:
+        z = zmax * np.linspace(0, 1, nz) ** rng.uniform(1.0, 1.6)
+    rmax = rng.uniform(30e3, 400e3)
+    x_off = 0.0 if rng.random() < 0.5 else rng.uniform(-500e3, 500e3)     # tables need not start at range 0
+    nr = int(rng.integers(3, 120))
+    r = x_off + (np.linspace(0, rmax, nr) if rng.random() < 0.6 else np.sort(np.concatenate([[0, rmax], rng.uniform(0, rmax, nr - 2)])))
+    slope = 0.0 if rng.random() < 0.4 else rng.uniform(-2e-3, 2e-3)
+    axis = rng.uniform(0.15, 0.5) * zmax
+    cin = np.array([munk(z, axis + slope * (ri - x_off)) for ri in r]) if slope else np.tile(munk(z, axis), (len(r), 1))
+    cpin = np.gradient(cin, z, axis=1, edge_order=1)
+    nb = int(rng.integers(4, 60))
+    br = x_off + (np.linspace(0, rmax, nb) if rng.random() < 0.5 else np.sort(np.concatenate([[0, rmax], rng.uniform(0, rmax, nb - 2)])))
+    floor = rng.uniform(0.7, 0.95) * zmax
+    depths = np.full(nb, floor) if rng.random() < 0.4 else floor + rng.uniform(0, 0.04) * zmax * np.sin((br - x_off) / rng.uniform(20e3, 90e3))
+    ba = np.degrees(np.arctan(np.gradient(depths, br)))
+    arrs = [cin, cpin, r, z, depths, br, ba]
+    mirrored = bool(rng.random() < 0.3)
+    if mirrored:   # the mirrored frame of a backwards shot (REF/launch_rays.py:684-714): negative, reversed ranges
+        arrs = [np.ascontiguousarray(cin[::-1]), np.ascontiguousarray(cpin[::-1]), -r[::-1], z,
+                np.ascontiguousarray(depths[::-1]), -br[::-1], -ba[::-1]]
+    rr = arrs[2]
+    x0 = rr[0] + rng.uniform(0.0, 0.3) * (rr[-1] - rr[0]) * (rng.random() < 0.5)
+    x1 = x0 + rng.uniform(0.3, 1.0) * (rr[-1] - x0)
+    src = rng.uniform(0.05, 0.6) * zmax
+    rtol = [1e-9, 1e-7, 1e-5][int(rng.integers(0, 3))]
+    th = np.linspace(-rng.uniform(5, 30), rng.uniform(5, 30), n_rays)
+    S = int(rng.integers(2, 60))
+    tb = bool(rng.random() < 0.8)
+    desc = (f"nz {len(z):5d} ({['uniform', 'pow2', 'stretched'][kind_z]}) nr {len(r):3d} nb {nb:2d} rtol {rtol:g} S {S:2d} "
+            f"range-dep {bool(slope)!s:5s} mirrored {mirrored!s:5s} x0 {x0:10.0f} x1 {x1:10.0f}")
+    return arrs, (src, x0, th), dict(x0=x0, x1=x1, S=S, rtol=rtol, terminate_backwards=tb), desc
