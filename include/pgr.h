@@ -45,9 +45,10 @@ extern "C" {
 /* flags for pgr_shoot_fan* */
 #define PGR_TERMINATE_BACKWARDS 1u /* REF/launch_rays.py:19,474 (default True) */
 #define PGR_SAMPLE_MAJOR 2u        /* T/z/p laid out [S][N] instead of [N][S] */
-#define PGR_EXACT_BISECTION 4u     /* locate events with brentq's exact ~42-step bisection on the
-                                      +-1 event (SCIPY/ivp.py:51-76) instead of the default
-                                      Newton-on-the-quartic + verified bracket of the same width */
+#define PGR_EXACT_BISECTION 4u     /* locate events with brentq's ~42-step bisection, the true +-1 event evaluated
+                                      at every iterate (SCIPY/ivp.py:51-76), instead of the default replay of the
+                                      same iterates that evaluates it only inside the rounding-noise band around
+                                      the root: the same root either way */
 
 #define PGR_SAVE_LINSPACE 8u       /* (device entry) the caller asserts r_save is exactly
                                       np.linspace(source_range, receiver_range, S); the kernel then

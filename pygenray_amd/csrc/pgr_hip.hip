@@ -130,9 +130,11 @@ struct FanArgs {
 //     rounded unless the exact quotient is within ~2^-104 of a rounding boundary (0 mismatches
 //     in 2e6 random operands, tests/test_hip_parity.py::test_arithmetic_building_blocks);
 //   * sqrt: v_rsq_f64 + Newton + one residual correction (0 mismatches in 2e6);
-//   * err^-0.2: Newton on y^-5 = err from an fp32 seed, <= 2 ulp (pow() is not correctly
-//     rounded in libm or ocml either); 10*ulp(t) by integer arithmetic (exact).
-// -DPGR_STRICT uses the compiler's IEEE divide/sqrt and pow(); -DPGR_FMA additionally allows
+//   * err ** -0.2, arcsin, sin: CORRECTLY ROUNDED (pgr_crmath.h) -- the reference calls the platform
+//     libm for them, which is faithful but not correctly rounded, so the oracle's ORC_MATH_CR mode (the
+//     same functions in binary128, rounded once) is what this file matches bit for bit;
+//     10*ulp(t) by integer arithmetic (exact).
+// -DPGR_STRICT uses the compiler's IEEE divide/sqrt; -DPGR_FMA additionally allows
 // contraction and a 2-ulp rsqrt (fastest, NOT within 1e-8 of the reference: experiments only).
 // ------------------------------------------------------------------------------------
 #ifdef PGR_STRICT
