@@ -112,6 +112,8 @@ struct FanArgs {
     uint32_t flags;
 };
 
+static_assert(alignof(FanArgs) == 8, "the fan kernel re-reads its FanArgs at kernel-argument offset 8");
+
 #define RUNNING (-1)
 
 // ------------------------------------------------------------------------------------
@@ -366,6 +368,13 @@ __device__ __forceinline__ int cell_search(double q, const double* __restrict__ 
 // gives the candidate cell, the next three nodes of zin (and of the profile) are read together
 // and a compare picks the cell -- two dependent LDS reads instead of a 13-step binary search
 // through L2 (the reference's default flat-earth grid: 36 -> 11 ms per 1e5-ray fan).
+// the next double above a finite x (the band arithmetic of the event locator)
+__device__ __forceinline__ double next_up(double x)
+{
+    const long long b = __double_as_longlong(x);
+    return __longlong_as_double((x == 0.0) ? 1LL : (b >= 0 ? b + 1 : b - 1));
+}
+
 template <bool LDS_TAB, int ZM>
 struct Ctx {
     static constexpr bool ZS = (ZM == 1 || ZM == 4);  // ZM == 4: ZS with dz == 1.0 (np.arange(0, 6000, 1)): no scaling at all
@@ -386,7 +395,6 @@ struct Ctx {
     // descriptor is read from memory where it is needed)
     const double h_inv_dz, h_dz, h_r0, h_dr, h_inv_dr;
     const double h_b_zmin, h_b_xlo, h_b_xhi, h_zhi_tol, h_zlo_tol, h_rlo_tol, h_rhi_tol;  // events()
-    const double h_c_lo, h_c_hi;
     const double h_b0, h_db, h_inv_db;  // bathy()
     const int h_nb, h_b_uniform;
     const double2* const h_tab;  // HBM table variant
@@ -407,7 +415,7 @@ struct Ctx {
           h_zq_c0(e_.zq_c0), h_zq_c1(e_.zq_c1), h_zq_c2(e_.zq_c2), h_zq_inv_span(e_.zq_inv_span),
           h_inv_dz(e_.inv_dz), h_dz(e_.dz), h_r0(e_.r0), h_dr(e_.dr),
           h_b_zmin(e_.b_zmin), h_b_xlo(e_.b_xlo), h_b_xhi(e_.b_xhi), h_zhi_tol(e_.zhi_tol),
-          h_zlo_tol(e_.zlo_tol), h_rlo_tol(e_.rlo_tol), h_rhi_tol(e_.rhi_tol), h_c_lo(e_.c_lo), h_c_hi(e_.c_hi), h_b0(e_.b0), h_db(e_.db),
+          h_zlo_tol(e_.zlo_tol), h_rlo_tol(e_.rlo_tol), h_rhi_tol(e_.rhi_tol), h_b0(e_.b0), h_db(e_.db),
           h_inv_db(e_.inv_db), h_nb(e_.nb), h_b_uniform(e_.b_uniform), h_tab(e_.tab),
           h_row_stride(e_.row_stride), h_z_uniform(e_.z_uniform), h_z_pow2(e_.z_pow2), h_z0(e_.z0),
           h_zin(e_.zin),
@@ -557,6 +565,10 @@ struct Ctx {
     __device__ __forceinline__ double bathy(double x) const
     {
         int i;
+        return bathy(x, i);
+    }
+    __device__ __forceinline__ double bathy(double x, int& i) const
+    {
         double xi, xi1;
         if (h_b_uniform) {
             i = cell_uniform(x, h_b0, h_db, h_inv_db, h_nb);
@@ -873,7 +885,7 @@ struct Dense {
 // (arange(S) * step + start, last point forced to x1 -- verified bitwise on the host) or loaded
 struct SaveGrid {
     const double* r;
-    double x0, x1, step, inv_step;
+    double x0, x1, step;
     int S, formula;
     __device__ __forceinline__ double at(int j) const
     {
@@ -881,7 +893,8 @@ struct SaveGrid {
         return r[j];
     }
     // np.argmin(np.abs(range_save - t)) (first minimum), REF/launch_rays.py:766-767
-    __device__ __forceinline__ int nearest(double t) const
+    // (inv_step = (S - 1) / (x1 - x0): a guess, the search around it decides)
+    __device__ __forceinline__ int nearest(double t, double inv_step) const
     {
         double g = (t - x0) * inv_step;
         g = fmin(fmax(g, 0.0), (double)(S - 1));
@@ -970,13 +983,14 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     const int S = a.S;
     constexpr bool save = (SAVE != 0);  // trajectories wanted (a.T != nullptr)
     const bool exact_samples = (SAVE == 2) && (a.flags & PGR_EXACT_SAMPLES) != 0;
-    const int64_t attempt_limit = 4 * a.max_steps + 4096;  // guard against endless rejection
+    // (max_steps <= 2^30, host checked; the counters are ints)
+    const int attempt_limit = (int)((4 * a.max_steps + 4096 < 0x7fffffff) ? 4 * a.max_steps + 4096 : 0x7fffffff);
     // PGR_STORED_SIGN: trajectories leave as pygenray stores them, z -> -z and p -> -p
     // (REF/ray_objects.py:51-52): a sign-bit xor, exact, and two host passes over 1.6 GB less
     const unsigned long long sgn = (a.flags & PGR_STORED_SIGN) ? 0x8000000000000000ULL : 0ULL;
 #define SGN(v) __longlong_as_double(__double_as_longlong(v) ^ (long long)sgn)
     SaveGrid G;
-    G.r = a.r_save; G.x0 = a.x0; G.x1 = a.x1; G.step = a.save_step; G.inv_step = a.inv_dsave;
+    G.r = a.r_save; G.x0 = a.x0; G.x1 = a.x1; G.step = a.save_step;
     G.S = S; G.formula = (SAVE == 1) ? 1 : a.save_formula;
 
     double t = a.x0, y0 = 0, y1 = 0, y2 = 0;
@@ -1128,7 +1142,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
             h_abs = too_small ? h_abs : h_abs * (accepted ? fac_acc : fac_rej);
             rejected = too_small ? rejected : reject;
             n_rej += reject ? 1 : 0;
-            const bool over = (int64_t)((unsigned)n_rej + (unsigned)n_steps) > attempt_limit;
+            const bool over = (n_rej + n_steps) > attempt_limit;
             status = too_small ? PGR_RAY_STEP_TOO_SMALL : ((reject & over) ? PGR_RAY_MAX_STEPS : status);
             PGR_STAMP(16);
 
@@ -1235,9 +1249,21 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                 waited = 0;
                 services++;
                 // =========================== SERVICE phase ===========================
+                // what only the service needs of the environment descriptor and of the kernel arguments is read
+                // HERE, through pointers the compiler cannot trace back (the empty asm): hoisted to the prologue
+                // these values sit in SGPRs across the step loop and push loop values out to VGPR lanes
+                const EnvDev* es_p = env_p;
+                asm volatile("" : "+s"(es_p));
+                const EnvDev& es = *es_p;
+                const char __attribute__((address_space(4))) * ks_p =
+                    (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+                asm volatile("" : "+s"(ks_p));
+                const FanArgs __attribute__((address_space(4))) & as = *(const FanArgs __attribute__((address_space(4))) *)(ks_p + 8);
+                const double svc_c_lo = es.c_lo, svc_c_hi = es.c_hi;
 #ifdef PGR_DBG_REPLAY
                 const unsigned long long dbg_s0 = __builtin_amdgcn_s_memtime();
                 unsigned long long dbg_s1 = dbg_s0, dbg_s4 = dbg_s0, dbg_s5 = dbg_s0, dbg_r0 = dbg_s0, dbg_r3 = dbg_s0;
+                unsigned long long dbg_n1 = dbg_s0, dbg_n2 = dbg_s0, dbg_n3 = dbg_s0, dbg_b1 = dbg_s0, dbg_b2 = dbg_s0;
 #endif
                 if (pend && parked) {
                     parked = false;
@@ -1274,7 +1300,8 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                         const bool bottom = (act == 2u);
                         const double q0 = D.q[1][0], q1 = D.q[1][1], q2 = D.q[1][2], q3 = D.q[1][3];
                         double bs = 0, be = 0;
-                        if (bottom) { bs = C.bathy(t); be = C.bathy(t_new); }
+                        int cell_s = 0, cell_e = 0;
+                        if (bottom) { bs = C.bathy(t, cell_s); be = C.bathy(t_new, cell_e); }
                         double zb = y1 + h * (q0 + q1 + q2 + q3);
                         double Fa = bottom ? (y1 - bs) : y1;  // F at s = 0: not yet crossed
                         double Fb = bottom ? (zb - be) : zb;  // F at s = 1: crossed
@@ -1283,19 +1310,26 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                         double xa = t, xb = t_new;
                         bool live = false;
                         const bool any_bottom = ballot64(bottom) != 0;  // (wave-uniform: skips the bathymetry look-up of a surface-only service)
+                        // the sea floor under a step that stays inside one bathymetry cell is its chord: Newton (which
+                        // only has to land inside the noise band, checked at its edges below) takes that instead of
+                        // a look-up per iterate
+                        const bool chord = ballot64(bottom && cell_s != cell_e) == 0;
                         if (pre) {
                             const double bslope = bottom ? (be - bs) : 0.0;  // per unit s
                             double lo = 0.0, hi = 1.0;
                             double sN = fdiv(Fa, Fa - Fb);  // secant start
                             double dFs = 0;
-                            // safeguarded Newton: four steps in a row (quadratic convergence from the secant
-                            // start: ~1e-3, 1e-6, 1e-12 of the step), more only for a lane that still moves
+                            // safeguarded Newton: three steps in a row (quadratic convergence from the secant
+                            // start: ~1e-3, 1e-6, 1e-12 of the step; the third one moves by less than the
+                            // tolerance), more only for a lane that still moves
                             for (int it = 0; it < 16; it++) {
                                 double zs = y1 + h * (sN * (q0 + sN * (q1 + sN * (q2 + sN * q3))));
                                 double dz = h * (q0 + sN * (2 * q1 + sN * (3 * q2 + sN * 4 * q3)));
                                 double F = zs, dF = dz;
                                 if (any_bottom) {
-                                    const double bq = C.bathy(t + sN * h);
+                                    double bq;
+                                    if (chord) bq = bs + sN * bslope;
+                                    else bq = C.bathy(t + sN * h);
                                     F = bottom ? zs - bq : zs;
                                     dF = bottom ? dz - bslope : dz;
                                 }
@@ -1308,8 +1342,11 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                                 if (!(sn >= lo && sn <= hi)) sn = 0.5 * (lo + hi);
                                 double ds = fabs(sn - sN);
                                 sN = sn;
-                                if (it >= 3 && ballot64(ds * h >= 1e-12 * (1.0 + fabs(t))) == 0) break;
+                                if (it >= 2 && ballot64(ds * h >= 1e-12 * (1.0 + fabs(t))) == 0) break;
                             }
+#ifdef PGR_DBG_REPLAY
+                            dbg_n1 = __builtin_amdgcn_s_memtime();
+#endif
                             const double xs = t + sN * h;
                             // E: rounding noise of F as the event evaluates it.  z(x) = h (Q p) + y_old: half an ulp
                             // of the result for the last add and ~4 roundings of terms <= |h| sum|Q|; the sea floor
@@ -1335,7 +1372,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
            Q7): with 0 < c <= c_hi (the table's maximum, a margin for the extrapolated sliver above the        \
            surface included) |p| c_hi < 1 settles both from p alone -- no table look-up */                    \
         double pc_ = pz_;                                                                                        \
-        if (ballot64(!((C.h_c_lo > 0) & (fabs(pz_) * C.h_c_hi < 1.0))) != 0) {                                    \
+        if (ballot64(!((svc_c_lo > 0) & (fabs(pz_) * svc_c_hi < 1.0))) != 0) {                                    \
             double c_, cp_;                                                                                      \
             C.lookup((X_), z_, c_, cp_);                                                                         \
             pc_ = pz_ * c_;                                                                                      \
@@ -1345,12 +1382,42 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
         BBOX_ = (z_ > C.h_zhi_tol) | (z_ < C.h_zlo_tol) | ((X_) < C.h_rlo_tol) | ((X_) > C.h_rhi_tol);           \
     } while (0)
                             bool ga, gb, bbox_a, bbox_b;
+#ifdef PGR_DBG_REPLAY
+                            asm volatile("" : "+v"(xa), "+v"(xb));
+                            dbg_n2 = __builtin_amdgcn_s_memtime();
+#endif
                             PGR_TRUE_EVENT(xa, ga, bbox_a);
                             PGR_TRUE_EVENT(xb, gb, bbox_b);
+#ifdef PGR_DBG_REPLAY
+                            dbg_n3 = __builtin_amdgcn_s_memtime();
+#endif
                             (void)bbox_a;
                             // with the bounding-box event also active its flip must lie beyond xb, so
                             // that the surface root is the earlier one (SCIPY/ivp.py:100-131)
                             live = (xa < xb) && !ga && gb && !(with_bbox && bbox_b);
+#ifndef PGR_NO_BAND_TABLE
+                            // The doubles strictly inside the band: one or two once the noise band is narrower than
+                            // an ulp of x (beyond ~100 km).  Evaluate the true event there as well, and if it flips
+                            // once the band shrinks to the flip itself, (last double not fired, first double fired):
+                            // every iterate of the replay is then decided by its position, no lane waits inside the
+                            // band for phase 2 and phase 2 evaluates nothing.  Wider or non-monotone bands stay as
+                            // they are and are evaluated iterate by iterate.
+                            {
+                                const double x1 = next_up(xa), x2 = next_up(x1), x3 = next_up(x2);
+                                const int m = !live ? 3 : (x1 >= xb) ? 0 : (x2 >= xb) ? 1 : (x3 >= xb) ? 2 : 3;
+                                bool g1 = true, g2 = true, bbox_q;
+                                if (ballot64(m == 1 || m == 2) != 0) { PGR_TRUE_EVENT(x1, g1, bbox_q); }
+                                if (ballot64(m == 2) != 0) { PGR_TRUE_EVENT(x2, g2, bbox_q); }
+                                (void)bbox_q;
+                                g1 = (m == 1 || m == 2) ? g1 : true;
+                                g2 = (m == 2) ? g2 : true;
+                                if (m <= 2 && (g2 || !g1)) {
+                                    const double nxa = g1 ? xa : (g2 ? x1 : x2);
+                                    xb = g1 ? x1 : (g2 ? x2 : xb);
+                                    xa = nxa;
+                                }
+                            }
+#endif
                         }
 #ifdef PGR_NO_REPLAY  // experiments: round 1's "a root within brentq's tolerance" (NOT bit-identical)
                         if (live) { best = xb; ev = bottom ? 1 : 0; }
@@ -1387,7 +1454,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                             bool lastc = true;
 #pragma unroll 4
                             for (int k = 0; k < n1; k++) {
-                                const double nw = plo + (phi - plo) / 2;
+                                const double nw = __builtin_fma(phi - plo, 0.5, plo);  // (phi - plo) / 2 is exact: one rounding either way
                                 const bool ge = (nw >= xb), le = (nw <= xa);
                                 phi = ge ? nw : phi;
                                 plo = le ? nw : plo;
@@ -1498,6 +1565,10 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                         double r0, r1, r2;
                         D.eval(t, y0, y1, y2, t_end, r0, r1, r2);
                         t = t_end; y0 = r0; y1 = r1; y2 = r2;
+#ifdef PGR_DBG_REPLAY
+                        asm volatile("" : "+v"(y0), "+v"(y1), "+v"(y2));
+                        dbg_b1 = __builtin_amdgcn_s_memtime();
+#endif
                         if (ev == 2) status = PGR_RAY_VERTICAL;
                         else if (ev == 3) status = PGR_RAY_BBOX;
                         else {
@@ -1506,30 +1577,34 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                             const double pc_b = y2 * c;
                             const PGR_ASIN_DD_T A_b = PGR_ASIN_DD(pc_b);
                             double theta = PGR_ASIN_DD_HI(A_b) * (180.0 / M_PI);  // ray_angle
+#ifdef PGR_DBG_REPLAY
+                            asm volatile("" : "+v"(theta));
+                            dbg_b2 = __builtin_amdgcn_s_memtime();
+#endif
                             double theta_b;
                             if (ev == 0) {
                                 theta_b = -theta;
                                 ns++;
                             } else {
                                 // beta = interp1d(depth_ranges, bottom_angles, 'cubic')(x)
-                                const double* xr = env.depth_ranges;
-                                if (!(t >= xr[0] && t <= xr[env.nb - 1])) {
+                                const double* xr = es.depth_ranges;
+                                if (!(t >= xr[0] && t <= xr[es.nb - 1])) {
                                     status = PGR_RAY_BETA_RANGE;
                                     theta_b = 0;
                                 } else {
                                     double beta = 0.0;
-                                    if (!env.beta_zero) {
+                                    if (!es.beta_zero) {
                                         int i;
                                         double xi;
-                                        if (env.b_uniform) {
-                                            i = cell_uniform(t, env.b0, env.db, env.inv_db, env.nb);
-                                            xi = grid_at(env.b0, env.db, i);
+                                        if (es.b_uniform) {
+                                            i = cell_uniform(t, es.b0, es.db, es.inv_db, es.nb);
+                                            xi = grid_at(es.b0, es.db, i);
                                         } else {
-                                            i = cell_search(t, xr, env.nb);
+                                            i = cell_search(t, xr, es.nb);
                                             xi = xr[i];
                                         }
                                         double u = t - xi;
-                                        const double* q = env.pp + 4 * i;
+                                        const double* q = es.pp + 4 * i;
                                         beta = q[0] + u * (q[1] + u * (q[2] + u * q[3]));
                                     }
                                     theta_b = 2 * beta - theta;
@@ -1537,14 +1612,14 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                                 }
                             }
                             if (status == RUNNING) {
-                                if ((a.flags & PGR_TERMINATE_BACKWARDS) && (fabs(theta_b) > 90))
+                                if ((as.flags & PGR_TERMINATE_BACKWARDS) && (fabs(theta_b) > 90))
                                     status = PGR_RAY_BACKWARD;
                                 else {
                                     // (theta_b = -theta at the surface and on a flat floor: the sine of minus an arcsine, cheaply)
                                     y2 = fdiv(PGR_SIN_REFLECT(theta_b * (M_PI / 180.0), pc_b, A_b), c);
                                     need_init = true;
                                     if (!(t < t_bound)) status = PGR_RAY_OK;
-                                    else if (n_steps > a.max_steps) status = PGR_RAY_MAX_STEPS;
+                                    else if (n_steps > max_steps32) status = PGR_RAY_MAX_STEPS;
                                 }
                             }
                         }
@@ -1584,7 +1659,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                     rejected = false;
                     need_init = false;
                     if (save) {
-                        jnext = G.nearest(t);
+                        jnext = G.nearest(t, as.inv_dsave);
                         rnext = G.at(jnext);
                     }
                 }
@@ -1594,7 +1669,9 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                     const int ln = threadIdx.x & 63;
                     // lanes 6..11: whole service; stage replay + Q; Newton + band edges; (replay: lanes 2-4); samples + root + reflection; init
                     fallbacks += (ln == 6) ? (int)(dbg_s6 - dbg_s0) : (ln == 7) ? (int)(dbg_s1 - dbg_s0) : (ln == 8) ? (int)(dbg_r0 - dbg_s1)
-                               : (ln == 9) ? (int)(dbg_s4 - dbg_r3) : (ln == 10) ? (int)(dbg_s5 - dbg_s4) : (ln == 11) ? (int)(dbg_s6 - dbg_s5) : 0;
+                               : (ln == 9) ? (int)(dbg_s4 - dbg_r3) : (ln == 10) ? (int)(dbg_s5 - dbg_s4) : (ln == 11) ? (int)(dbg_s6 - dbg_s5)
+                               : (ln == 12) ? (int)(dbg_n1 - dbg_s1) : (ln == 13) ? (int)(dbg_n2 - dbg_n1) : (ln == 14) ? (int)(dbg_n3 - dbg_n2)
+                               : (ln == 15) ? (int)(dbg_b1 - dbg_s4) : (ln == 16) ? (int)(dbg_b2 - dbg_b1) : (ln == 17) ? (int)(dbg_s5 - dbg_b2) : 0;
                 }
 #endif
             }
@@ -1604,6 +1681,14 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     if (valid) {
         bool ok = (status == PGR_RAY_OK);
         double nan = __longlong_as_double(0x7ff8000000000000LL);
+        // the output pointers are read from the kernel-argument segment HERE (through a pointer the
+        // compiler cannot trace back to the arguments): as ordinary arguments they are loaded in the
+        // prologue and hold 14 SGPRs across the step loop, which spills loop values to VGPR lanes
+        typedef const FanArgs __attribute__((address_space(4))) * KArgs;
+        const char __attribute__((address_space(4))) * kp =
+            (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kp));
+        const FanArgs __attribute__((address_space(4))) & a = *(KArgs)(kp + 8);  // (shadows the argument)
         if (save) {
             if (ok) {
                 // last column = exact final state (REF/launch_rays.py:775-777)

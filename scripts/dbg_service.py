@@ -16,7 +16,9 @@ for save in (False, True):
     d = fan.n_rej.cpu().numpy().astype(np.int64)
     n = d[1]
     names = {2: "replay phase 1", 3: "replay phase 2 (incl. evaluations)", 4: "  of which true-event evaluations", 5: "phase-2 iterations (count)",
-             6: "WHOLE SERVICE", 7: "stage replay + Q", 8: "Newton + band edges", 9: "(after replay, before samples)", 10: "samples of the truncated step + root + reflection (CR asin/sin)", 11: "restart (2 RHS, CR pow, events, nearest sample)"}
+             6: "WHOLE SERVICE", 7: "stage replay + Q", 8: "Newton + band edges", 9: "(after replay, before samples)", 10: "samples of the truncated step + root + reflection (CR asin/sin)", 11: "restart (2 RHS, CR pow, events, nearest sample)",
+             12: "  Newton (to the converged root)", 13: "  noise band E, nu, edges xa/xb", 14: "  true event at the two edges",
+             15: "  samples + state at the root", 16: "  table look-up + CR arcsin", 17: "  reflection (beta, CR sin, divide)"}
     print(f"save={save}: trips {d[0]}, services {n}; cycles per service:")
-    for k in range(2, 12):
+    for k in range(2, 18):
         print(f"   {names[k]:70s} {d[k] / n:10.1f}")

@@ -94,3 +94,10 @@ for i in hot[:2]:
     print(f"loop from {blocks[i][0]}: blocks {[blocks[j][0] for j in order][:12]}... {n} instructions on the fall-through path:", dict(c), "| s_mov_b32 of 32-bit literals:", lit)
     ops = Counter(t.split()[0] for j in order for t in blocks[j][1])
     print("   top opcodes:", ops.most_common(28))
+    if "--path" in sys.argv:
+        # the instructions of the path that are not plain fp64 arithmetic or table reads, in order, with their block
+        plain = ("v_mul_f64", "v_add_f64", "v_fma_f64", "v_fmac_f64", "ds_read_b128", "v_max_f64")
+        for j in order:
+            for t in blocks[j][1]:
+                if not t.startswith(plain):
+                    print(f"      {blocks[j][0]:12s} {t}")
