@@ -253,7 +253,7 @@ __device__ __forceinline__ double frsqrt(double x)
 }
 // err ** -0.2 for err in [1e-7, 1e4], correctly rounded (pgr_crmath.h; -DPGR_POW_2ULP: the 2-ulp
 // Newton iteration of round 1, 18 instructions shorter -- experiments only, NOT bit-identical)
-__device__ __forceinline__ double pow_m02(double x)
+__device__ __forceinline__ double pow_m02(double x, const double fifth = 0.2, const double kln2 = PGR_CR_POW_KLN2)
 {
 #ifdef PGR_POW_2ULP
     float xf = (float)x;
@@ -266,7 +266,7 @@ __device__ __forceinline__ double pow_m02(double x)
     }
     return y;
 #else
-    return pgr_cr_pow_m02(x);
+    return pgr_cr_pow_m02_k(x, fifth, kln2);
 #endif
 }
 // 10 * |nextafter(t, +inf) - t|, SCIPY/rk.py:119
@@ -394,7 +394,13 @@ struct Ctx {
     // wave-uniform copies of the fields the step loop touches (kept in SGPRs; the rest of the
     // descriptor is read from memory where it is needed)
     const double h_inv_dz, h_dz, h_r0, h_dr, h_inv_dr;
-    const double h_b_zmin, h_b_xlo, h_b_xhi, h_zhi_tol, h_zlo_tol, h_rlo_tol, h_rhi_tol;  // events()
+    const double h_zhi_tol, h_zlo_tol;  // events()
+    // events(): a caller whose x never leaves [x0, x1] (the fan kernel: the rays march from a.x0 to a.x1)
+    // declares that span; when it lies inside the table's range box and inside the bathymetry table,
+    // the range tests of the bounding-box event cannot fire and "z above the shallowest bathymetry
+    // node" alone rules the bottom event out: two thresholds on the step's common path instead of six
+    mutable int x_guard = 0;
+    mutable double zmin_eff = -INFINITY;
     const double h_b0, h_db, h_inv_db;  // bathy()
     const int h_nb, h_b_uniform;
     const double2* const h_tab;  // HBM table variant
@@ -414,14 +420,18 @@ struct Ctx {
           lds_zb(lzb), h_zb_z0(e_.zb_z0), h_zb_inv_w(e_.zb_inv_w), h_zb_B(e_.zb_B),
           h_zq_c0(e_.zq_c0), h_zq_c1(e_.zq_c1), h_zq_c2(e_.zq_c2), h_zq_inv_span(e_.zq_inv_span),
           h_inv_dz(e_.inv_dz), h_dz(e_.dz), h_r0(e_.r0), h_dr(e_.dr),
-          h_b_zmin(e_.b_zmin), h_b_xlo(e_.b_xlo), h_b_xhi(e_.b_xhi), h_zhi_tol(e_.zhi_tol),
-          h_zlo_tol(e_.zlo_tol), h_rlo_tol(e_.rlo_tol), h_rhi_tol(e_.rhi_tol), h_b0(e_.b0), h_db(e_.db),
+          h_zhi_tol(e_.zhi_tol), h_zlo_tol(e_.zlo_tol), h_b0(e_.b0), h_db(e_.db),
           h_inv_db(e_.inv_db), h_nb(e_.nb), h_b_uniform(e_.b_uniform), h_tab(e_.tab),
           h_row_stride(e_.row_stride), h_z_uniform(e_.z_uniform), h_z_pow2(e_.z_pow2), h_z0(e_.z0),
           h_zin(e_.zin),
           h_inv_dr(e_.inv_dr), h_rin(e_.rin), h_nz(e_.nz), h_nr(e_.nr), h_r_uniform(e_.r_uniform)
     {
         r_lo = 1.0; r_hi = 0.0; r_yden = 1.0; r_hi2 = 0.0; r_i = 0;  // empty interval: first use refills
+    }
+    __device__ __forceinline__ void declare_span(double x0, double x1) const
+    {
+        x_guard = (x0 <= x1) && (x0 >= e.rlo_tol) && (x1 <= e.rhi_tol) && (x0 >= e.b_xlo) && (x1 <= e.b_xhi);
+        zmin_eff = x_guard ? e.b_zmin : -INFINITY;
     }
 
     __device__ __forceinline__ int cell_z(double z, double& zj, double& zj1) const
@@ -684,7 +694,10 @@ struct Ctx {
         // (minus a margin for the interpolation's rounding) and x is inside the bathymetry table;
         // vertical: only |pc| within 2e-10 of 1 can reach 90 - 1e-3 degrees.  Both tests sit in ONE
         // rarely entered block: every skipped block is a taken branch on the step's critical path.
-        const bool near_bottom = (pc > 0) & (pc <= 1.0) & !((z < h_b_zmin) & (x >= h_b_xlo) & (x <= h_b_xhi));
+        // (without a declared span: the full test)
+        bool above = (z < zmin_eff);
+        if (__builtin_expect(!x_guard, 0)) above = (z < e.b_zmin) & (x >= e.b_xlo) & (x <= e.b_xhi);
+        const bool near_bottom = (pc > 0) & (pc <= 1.0) & !above;
         const bool near_vertical = (fabs(pc) > k_vert) & (fabs(pc) <= 1.0);
         if (near_bottom | near_vertical) {
             if (near_bottom) {
@@ -695,7 +708,9 @@ struct Ctx {
                 if (fabs(th) > (90 - 1e-3)) g |= 4u;
             }
         }
-        if ((z > h_zhi_tol) | (z < h_zlo_tol) | (x < h_rlo_tol) | (x > h_rhi_tol)) g |= 8u;
+        bool outside = (z > h_zhi_tol) | (z < h_zlo_tol);
+        if (__builtin_expect(!x_guard, 0)) outside |= (x < e.rlo_tol) | (x > e.rhi_tol);
+        if (outside) g |= 8u;
         return g;
     }
 };
@@ -961,6 +976,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     }
     __syncthreads();
     const Ctx<LDS_TAB, ZM> C(env, lds_tab, lds_z, lds_zb, lds_bx);
+    C.declare_span(a.x0, a.x1);
     // waves are dealt to workgroups round-robin (wave w of block b = global wave w*grid + b):
     // neighbouring launch angles cost alike, so a strided deal balances the CUs
     int64_t gwave = (int64_t)(threadIdx.x >> 6) * gridDim.x + blockIdx.x;
@@ -978,7 +994,8 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     const int64_t ray = gwave * 64 + (threadIdx.x & 63);
     const bool valid = (gwave >= 0) && (ray < a.N);
     double SAFETY = 0.9, MIN_FACTOR = 0.2, MAX_FACTOR = 10,
-           SQRT3 = 1.7320508075688772, INV_SQRT3 = 0.57735026918962584;
+           SQRT3 = 1.7320508075688772, INV_SQRT3 = 0.57735026918962584,
+           POW_FIFTH = 0.2, POW_KLN2 = PGR_CR_POW_KLN2;
     const double rtol = a.rtol, atol = a.atol, t_bound = a.x1;
     const int S = a.S;
     constexpr bool save = (SAVE != 0);  // trajectories wanted (a.T != nullptr)
@@ -1090,6 +1107,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
         PGR_PIN(C.k_c2); PGR_PIN(C.k_c3); PGR_PIN(C.k_c4); PGR_PIN(C.k_c5); PGR_PIN(C.k_tiny); PGR_PIN(C.k_vert);
         PGR_PIN(SAFETY); PGR_PIN(MIN_FACTOR); PGR_PIN(MAX_FACTOR);
         PGR_PIN(SQRT3); PGR_PIN(INV_SQRT3);
+        PGR_PIN(POW_FIFTH); PGR_PIN(POW_KLN2);
 #undef PGR_PIN
     }
     // One trip = one step attempt of every stepping lane, THEN the gate that decides whether the
@@ -1135,7 +1153,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
             // max(MIN_FACTOR, nan) give)
             const bool accepted = !too_small && (error_norm < 1);
             const bool reject = !too_small && !accepted;
-            const double pw = SAFETY * pow_m02(error_norm);
+            const double pw = SAFETY * pow_m02(error_norm, POW_FIFTH, POW_KLN2);
             double fac_acc = (pw < MAX_FACTOR) ? pw : MAX_FACTOR;
             fac_acc = (rejected && !(fac_acc < 1)) ? 1.0 : fac_acc;
             const double fac_rej = (pw > MIN_FACTOR) ? pw : MIN_FACTOR;
@@ -1379,7 +1397,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
         }                                                                                                        \
         const double bd_ = any_bottom ? C.bathy(X_) : 0.0;                                                       \
         FIRED_ = bottom ? ((pc_ > 0) & (pc_ <= 1.0) & (z_ > bd_)) : ((z_ < 0) & (pc_ < 0) & (pc_ >= -1.0));       \
-        BBOX_ = (z_ > C.h_zhi_tol) | (z_ < C.h_zlo_tol) | ((X_) < C.h_rlo_tol) | ((X_) > C.h_rhi_tol);           \
+        BBOX_ = (z_ > C.h_zhi_tol) | (z_ < C.h_zlo_tol) | ((X_) < es.rlo_tol) | ((X_) > es.rhi_tol);             \
     } while (0)
                             bool ga, gb, bbox_a, bbox_b;
 #ifdef PGR_DBG_REPLAY

@@ -3,7 +3,8 @@ import sys
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
 from pygenray_amd import _lib
 VARIANTS = {"pow2ulp": ["-DPGR_POW_2ULP"], "noreplay": ["-DPGR_NO_REPLAY"], "libmtrig": ["-DPGR_LIBM_TRIG"],
-            "exactrsq": ["-DPGR_EXACT_RSQRT"], "dbgreplay": ["-DPGR_DBG_REPLAY"], "svc2": [], "svc2e": ["-DPGR_EPI_ARGS"], "svc3e": ["-DPGR_EPI_ARGS"], "dbgsvc2": ["-DPGR_DBG_REPLAY"], "nobandtab": ["-DPGR_NO_BAND_TABLE"],
+            "exactrsq": ["-DPGR_EXACT_RSQRT"], "dbgreplay": ["-DPGR_DBG_REPLAY"], "nobandtab": ["-DPGR_NO_BAND_TABLE"],
+            "plain": [],
             "timing": ["-DPGR_TIMING"], "pinlit": ["-DPGR_PIN_LITERALS=1"], "pinlit_nop": ["-DPGR_PIN_LITERALS=1", "-DPGR_PIN_P=0"], "nopin_p": ["-DPGR_PIN_P=0"]}
 for name in (sys.argv[1:] or VARIANTS):
     print(name, _lib.build(force=True, out=_lib.CSRC + f"/../../scripts/ab/{name}.so", extra_flags=VARIANTS[name], verbose=True), flush=True)
