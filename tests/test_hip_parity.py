@@ -257,6 +257,20 @@ def test_dropped_rays_and_statuses(lib):
     y0 = y0_for(oracle, arrs, 500.0, 0.0, [14.0, 2.0])
     g, o, _ = gpu_vs_oracle(lib, arrs, y0, 0.0, 50e3, 26, "bbox")
     assert g["status"][0] == 2 and g["status"][1] == 0
+    # the fan's span [x0, x1] reaches beyond the tables (the kernel then keeps the range tests of the
+    # bounding-box event and of the bottom pre-filter on every step): receiver behind the last table column
+    # -> every ray leaves the box in range; bathymetry table shorter than the span -> extrapolated sea floor
+    arrs = munk_arrays(50e3, nr=20, z=np.linspace(0, 6000, 601))
+    y0 = y0_for(oracle, arrs, 500.0, 0.0, [14.0, 2.0, -9.0])
+    g, o, _ = gpu_vs_oracle(lib, arrs, y0, 0.0, 60e3, 26, "receiver beyond the table")
+    assert np.all(g["status"] == 2)
+    arrs = munk_arrays(50e3, nr=20, z=np.linspace(0, 6000, 601))
+    arrs[5] = np.linspace(5e3, 30e3, 20)                     # depth_ranges cover 5..30 km of the 0..50 km shot
+    arrs[4] = np.linspace(4000.0, 4600.0, 20)
+    arrs[6] = np.degrees(np.arctan(np.gradient(arrs[4], arrs[5])))
+    y0 = y0_for(oracle, arrs, 500.0, 0.0, np.linspace(-16, 16, 40))
+    g, o, _ = gpu_vs_oracle(lib, arrs, y0, 0.0, 50e3, 26, "bathymetry table shorter than the shot")
+    assert (g["n_bott"] > 0).any()
 
 
 def test_near_vertical_rays_do_not_crash(lib):
