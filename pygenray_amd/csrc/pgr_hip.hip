@@ -549,11 +549,16 @@ struct Ctx {
             f.v10 = f.v00;  // range independent: rows are bitwise identical
             f.v11 = f.v01;
         } else {
-            const double2* row = h_tab + (size_t)i * h_row_stride + j;
-            f.v00 = row[0];
-            f.v01 = row[1];
-            f.v10 = row[h_row_stride];
-            f.v11 = row[h_row_stride + 1];
+            // (the table pointer comes out of the descriptor, i.e. out of memory, so the compiler takes it for a
+            // generic pointer: flat_load + a wait on both counters; it IS global memory)
+            typedef double __attribute__((ext_vector_type(2))) d2v;
+            typedef const d2v __attribute__((address_space(1))) * GlobalTab;
+            const GlobalTab row = (GlobalTab)h_tab + (size_t)i * h_row_stride + j;
+            const d2v t00 = row[0], t01 = row[1], t10 = row[h_row_stride], t11 = row[h_row_stride + 1];
+            f.v00 = make_double2(t00.x, t00.y);
+            f.v01 = make_double2(t01.x, t01.y);
+            f.v10 = make_double2(t10.x, t10.y);
+            f.v11 = make_double2(t11.x, t11.y);
         }
         return f;
     }
