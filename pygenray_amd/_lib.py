@@ -122,7 +122,7 @@ def _relayout(td, verbose):
 
 
 def build(force=False, verbose=False, out=None, extra_flags=()):
-    """Compile csrc/pgr_hip.hip for gfx950 (cross-compiles without a GPU): hipcc, then the
+    """Compile csrc/pgr_hip.hip (+ pgr_device.h, pgr_fan_kernel.h, pgr_crmath.h) for gfx950 (cross-compiles without a GPU): hipcc, then the
     instruction-layout pass over its assembly (_relayout; PGR_NO_RELAYOUT=1 or any failure of that
     pass leaves the plain hipcc build in place).  `out` / `extra_flags`: build a variant library
     somewhere else (A/B experiments, scripts/kbench.py --lib); the default builds the product."""
@@ -131,7 +131,8 @@ def build(force=False, verbose=False, out=None, extra_flags=()):
     LIB_PATH = out or globals()["LIB_PATH"]
     src = os.path.join(CSRC, "pgr_hip.hip")
     hdr = os.path.join(_HERE, "..", "include", "pgr.h")
-    deps = [src, hdr, os.path.join(CSRC, "pgr_crmath.h"), os.path.join(_HERE, "_isa_layout.py")]
+    deps = [src, hdr, os.path.join(_HERE, "_isa_layout.py")] + [
+        os.path.join(CSRC, h) for h in ("pgr_crmath.h", "pgr_device.h", "pgr_fan_kernel.h")]
     if not force and os.path.exists(LIB_PATH):
         if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
             return LIB_PATH

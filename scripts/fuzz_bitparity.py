@@ -2,7 +2,7 @@
 environments and shots of tests/helpers.random_case.  Every ray must agree bit for bit -- status,
 bounce counts, accepted and rejected steps, end state, every sample (SciPy order) -- except the
 documented 1/sqrt(1 - 2^-53) class (at most 1 in 1000).
-usage: fuzz_bitparity.py [n_envs] [lib.so]"""
+usage: fuzz_bitparity.py [n_envs | seed,seed,...] [lib.so]"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -11,13 +11,15 @@ import oracle
 from helpers import y0_for, random_case
 from pygenray_amd import _lib
 
-n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+arg = sys.argv[1] if len(sys.argv) > 1 else "60"
+seeds = [int(v) for v in arg.split(",") if v] if "," in arg else list(range(int(arg)))
+n_seeds = len(seeds)
 if len(sys.argv) > 2:
     _lib.LIB_PATH = os.path.abspath(sys.argv[2])
 tot = odd = 0
 worst = []
 t_start = time.time()
-for seed in range(n_seeds):
+for seed in seeds:
     arrs, (src, x0, th), kw, desc = random_case(seed)
     y0 = y0_for(oracle, arrs, src, x0, th)
     env = _lib.EnvHandle(*arrs)
