@@ -321,6 +321,44 @@ def test_layouts_and_end_state_only(lib):
         lib.EnvHandle(arrs[0], arrs[1], arrs[2], arrs[3], arrs[4][:3], arrs[5][:3], arrs[6][:3])
 
 
+def test_two_host_threads_two_environments(lib):
+    """The boundary holds no process-wide state (SURVEY 8(b) "callable from one host thread per GPU"): two host
+    threads, each with its own environment (different tables, different scheduling options, its own stream),
+    shoot fans at the same time; every result equals the single-threaded one bit for bit.  A third thread
+    shares the first thread's environment (the library serialises its launches)."""
+    import threading
+    arrs_a = munk_arrays(100e3)
+    arrs_b = munk_arrays(100e3, nr=41, sofar_slope=2e-4)                     # range dependent: the HBM-table kernels
+    y0_a = y0_for(oracle, arrs_a, 1000.0, 0.0, np.linspace(-19, 19, 700))
+    y0_b = y0_for(oracle, arrs_b, 600.0, 0.0, np.linspace(-17, 17, 900))
+    env_a, env_b = lib.EnvHandle(*arrs_a), lib.EnvHandle(*arrs_b)
+    env_b.set_option("park", 32, 8)
+    env_b.set_option("placement", 1)
+    ref_a = env_a.shoot_fan(y0_a, 0.0, 100e3, 33)
+    ref_b = env_b.shoot_fan(y0_b, 0.0, 100e3, 17, sample_major=True)
+    errors = []
+
+    def work(env, y0, S, kw, ref, n):
+        try:
+            for _ in range(n):
+                g = env.shoot_fan(y0, 0.0, 100e3, S, **kw)
+                for k in ("T", "z", "p", "end", "status", "n_bott", "n_surf", "n_steps", "n_rej"):
+                    if not np.array_equal(g[k], ref[k], equal_nan=(g[k].dtype.kind == "f")):
+                        errors.append(f"{k} differs")
+        except Exception as e:   # noqa: BLE001 -- reported by the main thread
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(env_a, y0_a, 33, {}, ref_a, 6)),
+          threading.Thread(target=work, args=(env_b, y0_b, 17, dict(sample_major=True), ref_b, 6)),
+          threading.Thread(target=work, args=(env_a, y0_a, 33, {}, ref_a, 4))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors[:5]
+    assert_bit_parity(ref_a, oracle.shoot_fan(*arrs_a, y0_a, 0.0, 100e3, 33, math=oracle.MATH_CR), "thread test, env a", samples=False)
+
+
 def test_bucketed_depth_search_equals_binary_search(lib):
     """Non-uniform zin (the reference's default flat-earth grid, and a strongly graded one): the
     bucket-table cell search in LDS returns the cells of np.searchsorted -- every output bit equals
