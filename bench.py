@@ -212,6 +212,17 @@ def main(argv=None):
             print(f"error: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
         sys.exit(2)
 
+    # stdout carries exactly ONE line, rank 0's JSON: whatever the libraries under us print there (RCCL's
+    # version banner at the first collective, for one) goes to stderr instead -- file descriptor 1 is pointed at
+    # stderr for the whole run and the line is written to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(obj) + "\n").encode())
+
     import torch
     import torch.distributed as dist
     if args.launcher_only:
@@ -221,7 +232,7 @@ def main(argv=None):
         t = torch.ones(1)
         dist.all_reduce(t)
         if rank == 0:
-            print(json.dumps({"launcher_only": True, "n_gpus": world, "ranks_joined": int(t.item())}))
+            emit({"launcher_only": True, "n_gpus": world, "ranks_joined": int(t.item())})
         dist.barrier()
         dist.destroy_process_group()
         sys.exit(0 if int(t.item()) == args.gpus else 3)
@@ -379,7 +390,7 @@ def main(argv=None):
             out["cpu_baseline_c"] = cpu_baseline_c(arrs)
         if world == 1 and not args.no_eigenray:
             out["eigenray"] = eigenray_leg(env_obj, args.eigen_rays)
-        print(json.dumps(out))
+        emit(out)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
