@@ -201,21 +201,20 @@ __device__ __forceinline__ double frsqrt(double x)
     double g = x * y;
     double d = fma(-g, g, x);
     double s = fma(d * 0.5, y, g);   // RN(sqrt x)
+    // y made ODD (one v_or_b32): the classic exception of Newton-Raphson reciprocals is a divisor with an
+    // all-ones significand, here s = RN(sqrt x) = 1 - 2^-53 (x in {1 - 2^-53, 1 - 2^-52}: a stage within
+    // |p c| < 1.7e-8 of a turning point, 2 rays in 10 000 of the headline fan, found by scripts/trace_diff.py),
+    // where 1/s = 1 + 2^-53 + 2^-106 sits 2^-106 above a tie: with the even neighbour y = 1 the correction below
+    // is 1 + 2^-53 exactly and rounds to even, 1 instead of 1 + 2^-52; with the odd neighbour y = 1 + 2^-52 the
+    // residual is r = -2^-53 + 2^-105 (exact) and y + y r = 1 + 2^-53 + 2^-157 rounds up as it must.  Everywhere
+    // else y moves by at most an ulp (it is good to ~2^-51 either way).  Against IEEE 1/sqrt on the device: 0
+    // differences in 13 M operands, the doubles next to 1, 1/4 and 4 included (test_arithmetic_building_blocks);
+    // before: exactly those two x per binade, and the 0.008 % of the rays that met them.
+    y = __longlong_as_double(__double_as_longlong(y) | 1LL);
     double r = fma(-s, y, 1.0);      // y ~ 1/s to ~4e-15
     // one correction: y (1 + r) = 1/s to ~2e-29 relative, rounded once by the fma -- RN(1/s)
     // unless 1/s lies within ~2^-96 (relative) of a rounding boundary, the same class as fdiv().
-    // ONE input class is that close: s = 1 - 2^-53 (all-ones significand -- the classic exception of
-    // Newton-Raphson reciprocals), where 1/s = 1 + 2^-53 + 2^-106 sits 2^-106 above a tie and the fma
-    // returns 1 instead of 1 + 2^-52.  It is reached by x = 1 - c^2 p^2 in {1 - 2^-53, 1 - 2^-52}, i.e.
-    // a stage that lands within |p c| < 1.7e-8 of a turning point: ~1e-6 per step, 2 rays in 10 000 of
-    // the headline fan (scripts/trace_diff.py found it).  The select below repairs it exactly; it costs
-    // 2-3 instructions in each of the 7 right-hand sides of an attempt (+2 % on the critical path), so
-    // the product leaves it out and DESIGN.md section 4 reports the 99.98 % it leaves -- build with
-    // -DPGR_EXACT_RSQRT to see the last rays fall into place.
     double out = fma(y, r, y);
-#ifdef PGR_EXACT_RSQRT
-    out = (s == 0x1.fffffffffffffp-1) ? 0x1.0000000000001p+0 : out;
-#endif
     return out;
 #else
     return 1 / sqrt(x);

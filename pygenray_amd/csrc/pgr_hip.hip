@@ -272,9 +272,6 @@ extern "C" const char* pgr_build_info(void)
 #else
         info += "reference order, correctly rounded div/sqrt/pow/asin/sin";
 #endif
-#ifdef PGR_EXACT_RSQRT
-        info += ", exact 1/sqrt";
-#endif
 #ifdef PGR_POW_2ULP
         info += ", 2-ulp pow (NOT bit-identical)";
 #endif

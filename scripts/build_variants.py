@@ -3,7 +3,7 @@ import sys
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
 from pygenray_amd import _lib
 VARIANTS = {"pow2ulp": ["-DPGR_POW_2ULP"], "noreplay": ["-DPGR_NO_REPLAY"], "libmtrig": ["-DPGR_LIBM_TRIG"],
-            "exactrsq": ["-DPGR_EXACT_RSQRT"], "dbgreplay": ["-DPGR_DBG_REPLAY"], "nobandtab": ["-DPGR_NO_BAND_TABLE"],
+            "dbgreplay": ["-DPGR_DBG_REPLAY"], "nobandtab": ["-DPGR_NO_BAND_TABLE"],
             "plain": [],
             "timing": ["-DPGR_TIMING"], "pinlit": ["-DPGR_PIN_LITERALS=1"], "pinlit_nop": ["-DPGR_PIN_LITERALS=1", "-DPGR_PIN_P=0"], "nopin_p": ["-DPGR_PIN_P=0"]}
 for name in (sys.argv[1:] or VARIANTS):

@@ -1,7 +1,6 @@
 """Randomised BIT-PARITY sweep, GPU vs the oracle in its correctly-rounded-libm mode, over the random
 environments and shots of tests/helpers.random_case.  Every ray must agree bit for bit -- status,
-bounce counts, accepted and rejected steps, end state, every sample (SciPy order) -- except the
-documented 1/sqrt(1 - 2^-53) class (at most 1 in 1000).
+bounce counts, accepted and rejected steps, end state, every sample (SciPy order).
 usage: fuzz_bitparity.py [n_envs | seed,seed,...] [lib.so]"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
