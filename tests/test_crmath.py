@@ -60,6 +60,43 @@ def test_asin_and_sin_are_correctly_rounded(crh):
     assert np.array_equal(crh(3, w), oracle.math_fn("sin", w))
 
 
+def test_reflection_sine_short_form_equals_the_general_sine(crh):
+    """The reflection law at the surface and on a flat sea floor, sin(radians(-degrees(arcsin v)))
+    (REF/launch_rays.py:459-480), takes the sine from the arcsine's double-double value and a first-order term
+    (pgr_cr_sin_near_minus_asin): the same double as the correctly rounded sine of that argument."""
+    rng = np.random.default_rng(3)
+    v = np.concatenate([rng.uniform(-1, 1, N // 2), rng.uniform(-1, 1, N // 4) ** 5,
+                        np.sign(rng.uniform(-1, 1, N // 4)) * (1 - 10 ** rng.uniform(-16, -0.3, N // 4)),
+                        0.999 + np.arange(-2000, 2001) * 2.0 ** -53, [0.0, 1.0, -1.0, 0.75, -0.75, 1e-300]])
+    theta = oracle.math_fn("asin", v) * (180.0 / np.pi)
+    x = (-theta) * (np.pi / 180.0)
+    assert np.array_equal(crh(4, v), oracle.math_fn("sin", x))
+
+
+def test_hard_neighbourhoods(crh):
+    """Where correct rounding is hardest: the doubles next to arguments whose result is exactly representable
+    (x = 32^n for x ** -0.2 and x ** 0.2; v = 0, +-1/2 (asin = pi/6 is not exact, but the branch structure changes
+    near 0.75), +-1 for asin), next to the table nodes j/32 of the double-double sine / cosine and next to the
+    multiples of pi/2 of the sine's argument reduction."""
+    k = np.arange(-30_000, 30_001, dtype=np.float64)
+    for n in (-3, -1, 0, 1, 2):                                   # 32^n (1 + k ulp): results next to 2^-n
+        x = 32.0 ** n * (1.0 + k * 2.0 ** -52)
+        assert np.array_equal(crh(0, x), oracle.math_fn("pow_m02", x)), n
+        assert np.array_equal(crh(1, x), oracle.math_fn("pow_p02", x)), n
+    for c in (0.0, 0.5, 0.75, 0.7499999, 0.9, 2.0 ** -27):
+        v = np.concatenate([c + k * 2.0 ** -53 * max(c, 2.0 ** -60), -(c + k * 2.0 ** -53 * max(c, 2.0 ** -60))])
+        v = v[np.abs(v) <= 1]
+        assert np.array_equal(crh(2, v), oracle.math_fn("asin", v)), c
+    v = np.concatenate([1.0 - np.arange(0, 60_001) * 2.0 ** -53, -(1.0 - np.arange(0, 60_001) * 2.0 ** -53)])
+    assert np.array_equal(crh(2, v), oracle.math_fn("asin", v))
+    for j in (1, 7, 16, 25, 28, 29, 50):                          # sine: table nodes j/32 (j <= 28 tabulated) ...
+        w = j / 32.0 * (1.0 + k * 2.0 ** -52)
+        assert np.array_equal(crh(3, np.concatenate([w, -w])), oracle.math_fn("sin", np.concatenate([w, -w]))), j
+    for m in (1, 2, 3, 4):                                        # ... and the multiples of pi/2
+        w = m * (np.pi / 2) * (1.0 + k * 2.0 ** -52)
+        assert np.array_equal(crh(3, np.concatenate([w, -w])), oracle.math_fn("sin", np.concatenate([w, -w]))), m
+
+
 def test_the_platform_libm_is_faithful_but_not_correctly_rounded():
     """Why bit-identity needs the correctly rounded functions on BOTH sides: glibc's pow / asin /
     sin (what NumPy and SciPy call in this container, and the oracle's default MATH_LIBM mode)
