@@ -468,6 +468,8 @@ static int shoot_one(const orc_env *e, const double *y0_in, double source_range,
                      orc_stats *st, int64_t max_steps)
 {
     const double SAFETY = 0.9, MIN_FACTOR = 0.2, MAX_FACTOR = 10;
+    /* validate_tol, SCIPY/common.py:44-51: rtol = np.maximum(rtol, 100 * EPS) (with a warning) */
+    if (rtol < 100 * DBL_EPSILON) rtol = 100 * DBL_EPSILON;
     double x_int = source_range;
     double y[3] = {y0_in[0], y0_in[1], y0_in[2]};
     int nb = 0, ns = 0, status = ORC_OK;

@@ -629,6 +629,8 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
     a.N = N; a.S = save ? S : 1;
     if (flags & PGR_SAMPLE_MAJOR) { a.stride_ray = 1; a.stride_smp = N; }
     else { a.stride_ray = S; a.stride_smp = 1; }
+    // solve_ivp's validate_tol (SCIPY/common.py:44-51): an rtol below 100 EPS is raised to it (SciPy warns)
+    if (rtol < 100 * DBL_EPSILON) rtol = 100 * DBL_EPSILON;
     a.x0 = source_range; a.x1 = receiver_range; a.rtol = rtol; a.atol = atol;
     a.inv_dsave = (S > 1 && receiver_range != source_range) ? (double)(S - 1) / (receiver_range - source_range) : 0.0;
     // np.linspace: step = (stop - start) / (num - 1); y = arange(num) * step + start; y[-1] = stop

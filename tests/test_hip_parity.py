@@ -321,6 +321,16 @@ def test_layouts_and_end_state_only(lib):
         lib.EnvHandle(arrs[0], arrs[1], arrs[2], arrs[3], arrs[4][:3], arrs[5][:3], arrs[6][:3])
 
 
+def test_tolerances_outside_the_usual_range(lib):
+    """rtol from 1e-3 to 1e-12 and atol from 1e-12 to 1e-2 (SciPy's controller sees error norms from 1e-7 to
+    1e3 there, steps of metres to kilometres): bit for bit, bouncing rays included."""
+    arrs = munk_arrays(120e3, nr=13)
+    y0 = y0_for(oracle, arrs, 800.0, 0.0, np.linspace(-19.5, 19.5, 48))
+    # (the last one is below 100 EPS: solve_ivp raises it to 2.2e-14, SCIPY/common.py:44-51)
+    for rtol, atol in ((1e-3, 1e-6), (1e-12, 1e-6), (1e-11, 1e-12), (1e-6, 1e-2), (3e-14, 1e-9), (1e-15, 1e-9)):
+        gpu_vs_oracle(lib, arrs, y0, 0.0, 120e3, 25, f"rtol={rtol} atol={atol}", rtol=rtol, atol=atol)
+
+
 def test_two_host_threads_two_environments(lib):
     """The boundary holds no process-wide state (SURVEY 8(b) "callable from one host thread per GPU"): two host
     threads, each with its own environment (different tables, different scheduling options, its own stream),
