@@ -105,6 +105,8 @@ int pgr_env_query(const pgr_env* env, int what);
  * 745-784) with SciPy's RK45 defaults (REF/launch_rays.py:670-679: rtol given, atol 1e-6,
  * dense output, 4 terminal events).
  *
+ *   rtol, atol    as solve_ivp takes them: rtol > 0 (below 100 EPS it is raised to 100 EPS, SCIPY/common.py:44-51),
+ *                 atol >= 0
  *   y0[N][3]      initial [T, z, p]   (REF/launch_rays.py:140-144)
  *   r_save[S]     np.linspace(source_range, receiver_range, S), computed by the caller
  *   T,z,p         [N][S] (or [S][N] with PGR_SAMPLE_MAJOR); may all be NULL = end state only.
