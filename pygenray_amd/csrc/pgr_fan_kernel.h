@@ -524,7 +524,9 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                         const double xtol = 4 * DBL_EPSILON, brtol = 4 * DBL_EPSILON;
                         double cur = t_new, blk = t;
                         bool fcur = true;
+#ifdef PGR_DBG_REPLAY
                         int n1dbg = 0;
+#endif
 #ifdef PGR_DBG_REPLAY
                         const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -557,7 +559,10 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                                 plo = le ? nw : plo;
                                 lastc = ge | (lastc & !le);
                             }
-                            if (n1 > 0) { cur = lastc ? phi : plo; blk = lastc ? plo : phi; fcur = lastc; n1dbg = n1; }
+                            if (n1 > 0) { cur = lastc ? phi : plo; blk = lastc ? plo : phi; fcur = lastc; }
+#ifdef PGR_DBG_REPLAY
+                            n1dbg = n1;
+#endif
                         }
                         // phase 2: brentq's loop as it stands (scipy/optimize/Zeros/brentq.c) for the last few
                         // iterations, all lanes in lock step; the true event is evaluated (for the whole wave,
@@ -567,11 +572,15 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                         const unsigned long long dbg_t1 = __builtin_amdgcn_s_memtime();
                         unsigned long long dbg_ev = 0;
 #endif
+#ifdef PGR_DBG_REPLAY
                         int dbg_it = 0;
+#endif
                         double fcv = fcur ? 1.0 : 0.0;  // the event at cur, as a number (a carried bool costs more)
                         bool done = !live;
                         for (int it = 0; it < 200; it++) {
+#ifdef PGR_DBG_REPLAY
                             dbg_it++;
+#endif
                             const double dlt = (xtol + brtol * fabs(cur)) / 2;
                             const double sbis = (blk - cur) / 2;
                             done = !live | (fabs(sbis) < dlt);
