@@ -176,7 +176,7 @@ int pgr_arrival_histogram_device(int device, const double* t_end, int64_t t_stri
  *                            np.searchsorted (REF/integration_processes.py:152-157); a = 2 the bin table
  *                            even when the quadratic would do.  Tests compare the three.
  *   PGR_OPT_PARK             bounce-service batching: a wave services its parked (bounced) lanes when `a`
- *                            of them wait or the oldest waited `b` step attempts (default 64, 16)
+ *                            of them wait or the oldest waited `b` step attempts (default 64, 10)
  *   PGR_OPT_PLACEMENT        cost-aware wave scheduling for fans of 1-2 waves per SIMD: a = 2 (default) the
  *                            costliest waves get a SIMD to themselves / are paired with the cheapest, plus
  *                            issue priorities by cost quartile; 1 = priorities only; 0 = strided deal */

@@ -225,7 +225,7 @@ struct pgr_env {
     // No process-wide state: two host threads driving two GPUs keep two environments.
     int waves_per_block = 0;          // 0 = automatic
     int depth_search = 0;             // 0: automatic, 1: binary search only, 2: bucket table but no index polynomial (tests)
-    int park_lanes = 64, park_trips = 16;
+    int park_lanes = 64, park_trips = 10;
     int place = 2;                    // 0 off, 1 issue priorities only, 2 cost-aware placement + priorities
     hipStream_t stream = nullptr;     // the host-pointer entry's own stream (created on first use)
     EnvDev d{};

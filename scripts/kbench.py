@@ -19,7 +19,7 @@ ap.add_argument("--slope", type=float, default=0.0, help="sofar slope -> range d
 ap.add_argument("--S", type=int, default=1001)
 ap.add_argument("--lib", default=None)
 ap.add_argument("--place", type=int, default=-1)
-ap.add_argument("--park", type=int, nargs="*", default=[64, 16], help="pairs: lanes trips lanes trips ...")
+ap.add_argument("--park", type=int, nargs="*", default=[64, 10], help="pairs: lanes trips lanes trips ...")
 ap.add_argument("--exact", action="store_true")
 ap.add_argument("--exact-samples", action="store_true")
 a = ap.parse_args()
