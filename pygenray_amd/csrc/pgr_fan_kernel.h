@@ -109,6 +109,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     unsigned pk_active = 0;
     int waited = 0;
     int trips = 0, services = 0, fallbacks = 0;  // diagnostics (PGR_DEBUG_TRIPS)
+    const double min_step_bound = 10 * 0x1p-52 * fmax(fabs(a.x0), fabs(a.x1)) + 1e-300;  // see the attempt's head
     const int max_steps32 = (int)(a.max_steps < 0x7fffffff ? a.max_steps : 0x7fffffff);  // n_steps is an int
 #ifdef PGR_TIMING
     unsigned tacc[24];
@@ -203,9 +204,15 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
         PGR_STAMP(0);
         if (status == RUNNING && !parked && !need_init) {
             // ---- one attempt of RK45._step_impl, SCIPY/rk.py:111-176 ----
-            double min_step = min_step_of(t);
-            if (!rejected && h_abs < min_step) h_abs = min_step;  // clamp only on entry
-            bool too_small = h_abs < min_step;
+            // min_step = 10 ulp(t) <= 10 * 2^-52 max(|x0|, |x1|) =: min_step_bound for every t of the fan: a wave none
+            // of whose lanes steps below that bound needs neither the clamp nor the "step too small" test (exactly:
+            // h_abs >= bound >= min_step makes both no-ops) -- ten instructions of every attempt otherwise
+            bool too_small = false;
+            if (__builtin_expect(ballot64(h_abs < min_step_bound) != 0, 0)) {
+                double min_step = min_step_of(t);
+                if (!rejected && h_abs < min_step) h_abs = min_step;  // clamp only on entry
+                too_small = h_abs < min_step;
+            }
             double h = h_abs;
             double t_new = t + h;
             if ((t_new - t_bound) > 0) t_new = t_bound;
