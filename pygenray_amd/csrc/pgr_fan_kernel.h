@@ -111,6 +111,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     int trips = 0, services = 0, fallbacks = 0;  // diagnostics (PGR_DEBUG_TRIPS)
     const double min_step_bound = 10 * 0x1p-52 * fmax(fabs(a.x0), fabs(a.x1)) + 1e-300;  // see the attempt's head
     const int max_steps32 = (int)(a.max_steps < 0x7fffffff ? a.max_steps : 0x7fffffff);  // n_steps is an int
+    const int guard_limit = (max_steps32 < attempt_limit ? max_steps32 : attempt_limit);
 #ifdef PGR_TIMING
     unsigned tacc[24];
     for (int k = 0; k < 24; k++) tacc[k] = 0;
@@ -212,6 +213,9 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                 double min_step = min_step_of(t);
                 if (!rejected && h_abs < min_step) h_abs = min_step;  // clamp only on entry
                 too_small = h_abs < min_step;
+                // (RK45 raises "step size too small": the ray is dropped here and now; what the rest of this attempt
+                // does to the lane's state no longer matters, it is not accepted and never steps again)
+                if (too_small) status = PGR_RAY_STEP_TOO_SMALL;
             }
             double h = h_abs;
             double t_new = t + h;
@@ -243,11 +247,15 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
             double fac_acc = (pw < MAX_FACTOR) ? pw : MAX_FACTOR;
             fac_acc = (rejected && !(fac_acc < 1)) ? 1.0 : fac_acc;
             const double fac_rej = (pw > MIN_FACTOR) ? pw : MIN_FACTOR;
-            h_abs = too_small ? h_abs : h_abs * (accepted ? fac_acc : fac_rej);
-            rejected = too_small ? rejected : reject;
+            h_abs = h_abs * (accepted ? fac_acc : fac_rej);
+            rejected = reject;
             n_rej += reject ? 1 : 0;
-            const bool over = (n_rej + n_steps) > attempt_limit;
-            status = too_small ? PGR_RAY_STEP_TOO_SMALL : ((reject & over) ? PGR_RAY_MAX_STEPS : status);
+            // the two step-count guards: no lane has made more attempts than the wave has made trips
+            const bool guards_due = trips > guard_limit;
+            if (__builtin_expect(guards_due, 0)) {
+                const bool over = (n_rej + n_steps) > attempt_limit;
+                status = (reject & over) ? PGR_RAY_MAX_STEPS : status;
+            }
             PGR_STAMP(16);
 
             if (accepted) {
@@ -331,8 +339,9 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                     t = t_new; y0 = n0; y1 = n1; y2 = n2;
                     f0 = k70; f1 = k71; f2 = k72;
                     // (selects, not a skipped block: a taken branch costs more than these four instructions)
-                    status = ((t - t_bound) >= 0) ? PGR_RAY_OK  // SCIPY/base.py:197
-                                                  : ((n_steps > max_steps32) ? PGR_RAY_MAX_STEPS : status);
+                    status = ((t - t_bound) >= 0) ? PGR_RAY_OK : status;  // SCIPY/base.py:197
+                    if (__builtin_expect(guards_due, 0))
+                        status = (status == RUNNING && n_steps > max_steps32) ? PGR_RAY_MAX_STEPS : status;
                 }
                 PGR_STAMP(18);
             }
