@@ -58,6 +58,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-save", action="store_true", help="end state only (B_alg = 80 B)")
     ap.add_argument("--histogram", action="store_true",
                     help="each step also bins the arrival times (4096 bins) on the device and all-reduces the counts")
+    ap.add_argument("--range-dependent", action="store_true",
+                    help="BASELINE configs[2]: sofar axis sloping 2e-4 over 101 range columns (tables stay in HBM/L2); "
+                         "not the headline workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eigenray", action="store_true")
     ap.add_argument("--eigen-rays", type=int, default=1_000_000, help="fan size of the eigenray leg (configs[3])")
@@ -82,11 +85,13 @@ def spawn_ranks(args, argv):
     return subprocess.call(cmd, env=env)
 
 
-def munk_tables(r_max, nr=100):
+def munk_tables(r_max, nr=100, sofar_slope=0.0):
     import pygenray_amd as pr
     z = np.arange(0, 6000, 1.0)
     r = np.linspace(0.0, r_max, nr)
-    ssp = pr.DataArray(np.tile(pr.munk_ssp(z), (nr, 1)), dims=["range", "depth"],
+    # (configs[2]: c[i, :] = munk_ssp(z, sofar_depth = 1300 + slope * r_i), the pattern of REF/tests/test_physics.py:497)
+    c2 = np.array([pr.munk_ssp(z, 1300.0 + sofar_slope * ri) for ri in r]) if sofar_slope else np.tile(pr.munk_ssp(z), (nr, 1))
+    ssp = pr.DataArray(c2, dims=["range", "depth"],
                        coords={"range": r, "depth": z})
     bathy = pr.DataArray(np.full(nr, 5000.0), dims=["range"], coords={"range": r})
     env = pr.OceanEnvironment2D(ssp, bathy, flat_earth_transform=False)
@@ -260,7 +265,7 @@ def main(argv=None):
             sys.exit(3)
 
     _lib.load()
-    env_obj, arrs = munk_tables(RANGE_M)
+    env_obj, arrs = munk_tables(RANGE_M, nr=101, sofar_slope=2e-4) if args.range_dependent else munk_tables(RANGE_M)
     env = _lib.EnvHandle(*arrs, device=local_rank)
     if args.waves_per_block:
         env.set_option("waves_per_block", args.waves_per_block)
@@ -345,7 +350,7 @@ def main(argv=None):
             try:
                 tj = json.load(open(tpath))
                 key = f"{args.layout}{'' if save else '-nosave'}"
-                if key in tj and tj[key].get("rays") == fan.N:
+                if key in tj and tj[key].get("rays") == fan.N and not args.range_dependent:
                     traffic_gb = tj[key]["hbm_gb_per_launch"]
                     traffic = traffic_gb / (kern_ms * 1e-3)
                     valu = tj[key].get("valu_wave_instructions_per_launch")
@@ -357,7 +362,9 @@ def main(argv=None):
             "value": value, "unit": "ray-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"configs[1]: Munk SSP dz=1 m, {fan.N} launch angles per GPU "
+            "config": {"workload": (f"configs[2]: range-dependent Munk SSP (sofar axis + 2e-4 r, 101 columns) dz=1 m, "
+                                    if args.range_dependent else "configs[1]: Munk SSP dz=1 m, ")
+                                   + f"{fan.N} launch angles per GPU "
                                    "linspace(-20,20), 1000 km, rtol 1e-9, fp64"
                                    + (", + 4096-bin arrival-time histogram (configs[4] shape)" if args.histogram else ""),
                        "rays_per_gpu": fan.N, "num_range_save": S_SAVE if save else 0,
@@ -369,7 +376,8 @@ def main(argv=None):
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_gb_per_launch": traffic_gb, "traffic_source": tnote,
                          "algorithmic_gb_per_launch": local_steps * b_alg / 1e9,
-                         "kernel": f"pgr_fan_kernel<true, 4, {1 if save else 0}> (table in LDS, zin = j * 1 m, "
+                         "kernel": f"pgr_fan_kernel<{'false' if args.range_dependent else 'true'}, 4, {1 if save else 0}> "
+                                   f"(table in {'HBM/L2' if args.range_dependent else 'LDS'}, zin = j * 1 m, "
                                    f"{'linspace save grid' if save else 'end state only'})", "kernel_ms": kern_ms,
                          "bytes_per_ray_step": b_alg,
                          "note": "algorithmic bytes per SURVEY 8(d); the stepper keeps state in "
