@@ -13,22 +13,30 @@ the reference itself, ``tests/golden/make_golden.py``).
 import ctypes
 import os
 import subprocess
+import threading
 
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+# The arithmetic mode (libm / correctly rounded) is process-global state of the C library: every call that
+# sets it, runs and restores it holds this lock, so that two threads using the oracle at once (or an exception
+# between set and restore) cannot run a fan in the wrong mode -- the checker of every bit-parity test.
+_MATH_LOCK = threading.RLock()
 
 STATUS = {0: "ok", 1: "vertical", 2: "bbox", 3: "backward", 4: "step_too_small", 5: "max_steps",
           6: "bottom_angle_range", 7: "event_error"}
 
 
 def build(force=False):
-    so = os.path.join(_HERE, "libray_oracle.so")
+    """gcc build of ray_oracle.c.  ORACLE_SANITIZE=1 in the environment selects the AddressSanitizer +
+    UBSan build (`make asan`; the process must have libasan preloaded, tests/test_sanitizers.py)."""
+    san = os.environ.get("ORACLE_SANITIZE") == "1"
+    target = "_asan/libray_oracle.so" if san else "libray_oracle.so"
+    so = os.path.join(_HERE, target)
     src = os.path.join(_HERE, "ray_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "libray_oracle.so"],
-                              stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, "-B", target], stdout=subprocess.DEVNULL)
     return so
 
 
@@ -147,12 +155,13 @@ def math_fn(name, a, math=MATH_CR):
     fn = {"pow_m02": 0, "pow_p02": 1, "asin": 2, "sin": 3}[name]
     a = _c(a)
     out = np.empty(a.shape)
-    old = L.orc_get_math()
-    L.orc_set_math(int(math))
-    try:
-        L.orc_math_array(ctypes.c_int(fn), _p(a.reshape(-1)), _p(out.reshape(-1)), ctypes.c_int64(a.size))
-    finally:
-        L.orc_set_math(old)
+    with _MATH_LOCK:
+        old = L.orc_get_math()
+        L.orc_set_math(int(math))
+        try:
+            L.orc_math_array(ctypes.c_int(fn), _p(a.reshape(-1)), _p(out.reshape(-1)), ctypes.c_int64(a.size))
+        finally:
+            L.orc_set_math(old)
     return out
 
 
@@ -163,13 +172,21 @@ def shoot_fan(cin, cpin, rin, zin, depths, depth_ranges, bottom_angles, y0, sour
     (launch_rays.py:325-340) batched over rays.  Returns a dict of ODE-convention arrays.
     ``math``: MATH_LIBM / MATH_CR for this call (default: the current mode, initially libm)."""
     if math is not None:
-        old = get_math()
-        set_math(math)
-        try:
-            return shoot_fan(cin, cpin, rin, zin, depths, depth_ranges, bottom_angles, y0, source_range,
-                             receiver_range, num_range_save, rtol, atol, terminate_backwards, max_steps)
-        finally:
-            set_math(old)
+        with _MATH_LOCK:
+            old = get_math()
+            set_math(math)
+            try:
+                return shoot_fan(cin, cpin, rin, zin, depths, depth_ranges, bottom_angles, y0, source_range,
+                                 receiver_range, num_range_save, rtol, atol, terminate_backwards, max_steps)
+            finally:
+                set_math(old)
+    with _MATH_LOCK:   # (a call in the current mode must not overlap another thread's set / restore either)
+        return _shoot_fan_locked(cin, cpin, rin, zin, depths, depth_ranges, bottom_angles, y0, source_range,
+                                 receiver_range, num_range_save, rtol, atol, terminate_backwards, max_steps)
+
+
+def _shoot_fan_locked(cin, cpin, rin, zin, depths, depth_ranges, bottom_angles, y0, source_range,
+                      receiver_range, num_range_save, rtol, atol, terminate_backwards, max_steps):
     cin, cpin, rin, zin = _c(cin), _c(cpin), _c(rin), _c(zin)
     depths, depth_ranges, bottom_angles = _c(depths), _c(depth_ranges), _c(bottom_angles)
     y0 = _c(y0).reshape(-1, 3)
@@ -206,6 +223,7 @@ def trace_ray(cin, cpin, rin, zin, depths, depth_ranges, bottom_angles, y0, sour
     i64 = ctypes.c_int64
     L = lib()
     L.orc_trace_ray.restype = i64
+    _MATH_LOCK.acquire()
     old = get_math()
     if math is not None:
         set_math(math)
@@ -217,4 +235,5 @@ def trace_ray(cin, cpin, rin, zin, depths, depth_ranges, bottom_angles, y0, sour
                             _p(rows), i64(max_rows))
     finally:
         set_math(old)
+        _MATH_LOCK.release()
     return rows[:max(int(n), 0)]

@@ -54,6 +54,17 @@ struct EnvDev {
     // node and g' > 0 (host verified), so the cell of z is floor(g - 0.5) or the next one
     int z_quad;
     double zq_c0, zq_c1, zq_c2, zq_inv_span;
+    // ... and when a CUBIC in z itself estimates the node index to a small fraction of a cell (the flat-earth
+    // transform of a uniform grid IS a cubic in the depth: 1.5e-8 cells; a linspace grid that is not bitwise
+    // uniform: ~1e-12), two nodes instead of three are read and a z that belongs to the next cell is a rare
+    // event with its own (out-of-line) block: t = zc_g0 + z (zc_g1 + z (zc_g2 + z zc_g3)), evaluated with fma,
+    // satisfies j - 1 <= t < j + 1 for every z of cell j (zin[j] < z <= zin[j + 1]; host verified at every node
+    // with the device's own arithmetic, and the cubic is increasing), so trunc(t) is j or j - 1.  The reciprocal
+    // of the cell width zin[j + 1] - zin[j] is smooth too: zc_s0 + j (zc_s1 + j zc_s2) seeds the weight's
+    // division to <= 1e-8 (host verified for every cell) instead of v_rcp_f64.
+    int z_cubic;
+    double zc_g0, zc_g1, zc_g2, zc_g3;
+    double zc_s0, zc_s1, zc_s2;
 };
 
 struct FanArgs {
@@ -356,6 +367,7 @@ struct Ctx {
     const double h_zb_z0, h_zb_inv_w;
     const int h_zb_B;
     const double h_zq_c0, h_zq_c1, h_zq_c2, h_zq_inv_span;  // ZM == 3
+    mutable double h_zc_g0, h_zc_g1, h_zc_g2, h_zc_g3, h_zc_s0, h_zc_s1, h_zc_s2;  // ZM == 5 (mutable: the fan kernel pins them in VGPRs)
     // per-lane caches: x only moves forward, so the range cell (and the bathymetry cell under
     // the ray) changes once every ~10 km; keep its edges and the reciprocal of its width
     mutable double r_lo, r_hi, r_yden, r_hi2;  // r_hi2: upper edge of the NEXT cell (uniform rin) or r_hi
@@ -388,6 +400,8 @@ struct Ctx {
         : e(e_), lds(l), bx(lbx ? lbx : e_.depth_ranges), bd(lbx ? lbx + e_.nb : e_.depths), lds_z(lz),
           lds_zb(lzb), h_zb_z0(e_.zb_z0), h_zb_inv_w(e_.zb_inv_w), h_zb_B(e_.zb_B),
           h_zq_c0(e_.zq_c0), h_zq_c1(e_.zq_c1), h_zq_c2(e_.zq_c2), h_zq_inv_span(e_.zq_inv_span),
+          h_zc_g0(e_.zc_g0), h_zc_g1(e_.zc_g1), h_zc_g2(e_.zc_g2), h_zc_g3(e_.zc_g3),
+          h_zc_s0(e_.zc_s0), h_zc_s1(e_.zc_s1), h_zc_s2(e_.zc_s2),
           h_inv_dz(e_.inv_dz), h_dz(e_.dz), h_r0(e_.r0), h_dr(e_.dr), h_inv_dr(e_.inv_dr),
           h_zhi_tol(e_.zhi_tol), h_zlo_tol(e_.zlo_tol), h_b0(e_.b0), h_db(e_.db),
           h_inv_db(e_.inv_db), h_nb(e_.nb), h_b_uniform(e_.b_uniform), h_tab(e_.tab),
@@ -464,12 +478,29 @@ struct Ctx {
     struct Fetch {
         double2 v00, v01, v10, v11;
         double wy;
+        // ZM == 5: the weight is formed in the arithmetic half (blend), from the two nodes read here
+        double z, za, zb;
+        int i, j;
     };
     __device__ __forceinline__ Fetch fetch(int i, double z) const
     {
         Fetch f;
         int j;
-        if (ZM == 2 || ZM == 3) {
+        if (ZM == 5) {
+            // cubic index estimate (EnvDev::z_cubic): trunc(t) is the cell of z or the one below it.
+            // v_cvt_i32_f64 truncates, saturates and maps NaN to 0; one v_med3_i32 clamps.  Only the READS are
+            // issued here (two nodes of zin in one ds_read2_b64, the two table nodes); whether z belongs to the
+            // next cell, and the weight, are settled in blend() -- behind the independent work the stage
+            // macro puts between the two halves of a look-up.
+            const double t = fma(z, fma(z, fma(z, h_zc_g3, h_zc_g2), h_zc_g1), h_zc_g0);
+            j = clamp_index((int)t, h_nz - 2);
+            f.z = z; f.j = j; f.i = i;
+            f.za = lds_z[j];
+            f.zb = lds_z[j + 1];
+            f.wy = 0.0;
+            fetch_nodes(f, i, j);
+            return f;
+        } else if (ZM == 2 || ZM == 3) {
             // candidate cell j0 (zin[j0] < z <= zin[j0 + 2]) from the bin table, or from the
             // quadratic index estimate of a smooth grid; the three nodes from j0 on are fetched
             // together, then z > zin[j0 + 1] picks the upper cell
@@ -512,6 +543,12 @@ struct Ctx {
             // every cell exactly dz wide and dz a power of two: the division is an exact scaling
             f.wy = h_z_pow2 ? (z - zj) * h_inv_dz : fdiv(z - zj, zj1 - zj);
         }
+        fetch_nodes(f, i, j);
+        return f;
+    }
+    // the four corner nodes of (range cell i, depth cell j)
+    __device__ __forceinline__ void fetch_nodes(Fetch& f, int i, int j) const
+    {
         if (LDS_TAB) {
             f.v00 = lds[j];
             f.v01 = lds[j + 1];
@@ -529,11 +566,31 @@ struct Ctx {
             f.v10 = make_double2(t10.x, t10.y);
             f.v11 = make_double2(t11.x, t11.y);
         }
-        return f;
     }
     // ... and the arithmetic half: the reference's four-corner blend
-    __device__ __forceinline__ void blend(const Fetch& f, double wx, double& c, double& cp) const
+    __device__ __forceinline__ void blend(const Fetch& f_in, double wx, double& c, double& cp) const
     {
+        Fetch f = f_in;
+        if (ZM == 5) {
+            // z beyond the upper node of the estimated cell: it belongs to the next one (never further,
+            // EnvDev::z_cubic).  Rare (the estimate is good to ~1e-8 cells on the flat-earth grid), so the
+            // re-read sits in a block of its own behind a wave-uniform test.
+            // (the test is z > zb alone: a z below the deepest node also enters the block, and stays in its cell)
+            if (__builtin_expect(ballot64(f.z > f.zb) != 0, 0)) {
+                const bool up = (f.z > f.zb) & (f.j < h_nz - 2);
+                f.j += up ? 1 : 0;
+                f.za = lds_z[f.j];
+                f.zb = lds_z[f.j + 1];
+                fetch_nodes(f, f.i, f.j);
+            }
+            // (z - zin[j]) / (zin[j+1] - zin[j]), correctly rounded: the seed polynomial is good to 1e-8 (host
+            // verified per cell), one Newton step squares that, the Markstein correction squares it again
+            const double a = f.z - f.za, den = f.zb - f.za, jf = (double)f.j;
+            double y = fma(jf, fma(jf, h_zc_s2, h_zc_s1), h_zc_s0);
+            const double e = fma(-den, y, 1.0);
+            y = fma(y, e, y);
+            f.wy = fdiv_y(a, den, y);
+        }
         const double wy = f.wy;
         double a = (1 - wx) * (1 - wy), b = wx * (1 - wy), cc = (1 - wx) * wy, d = wx * wy;
         c = a * f.v00.x + b * f.v10.x + cc * f.v01.x + d * f.v11.x;
@@ -786,6 +843,11 @@ struct Dense {
 #else
 #define PGR_STAMP(k) do { } while (0)
 #endif
+// ZM == 5: the arithmetic half of a look-up starts with a (rarely taken) branch, and the compiler sinks the
+// independent sums placed in the read's shadow below it -- the wave would then wait for the LDS with nothing to
+// do.  An empty asm that takes the sums as operands keeps them in front of the branch.
+#define PGR_KEEP2(a_, b_) do { if (ZM == 5) asm volatile("" : "+v"(a_), "+v"(b_)); } while (0)
+#define PGR_KEEP6(a_, b_, c_, d_, e_, f_) do { if (ZM == 5) asm volatile("" : "+v"(a_), "+v"(b_), "+v"(c_), "+v"(d_), "+v"(e_), "+v"(f_)); } while (0)
 #define PGR_RK_STAGES(T_, H_)                                                                        \
     double k20, k21, k22, k30, k31, k32, k40, k41, k42, k50, k51, k52, k60, k61, k62, k70, k71, k72, \
         cs;                                                                                          \
@@ -806,6 +868,8 @@ struct Dense {
     double a31 = f1 * vA31, a32 = f2 * vA31, a41 = f1 * vA41, a42 = f2 * vA41, a51 = f1 * vA51,           \
            a52 = f2 * vA51, a61 = f1 * vA61, a62 = f2 * vA61;                                           \
     double bs0 = f0 * vB1, bs1 = f1 * vB1, bs2 = f2 * vB1, es0 = f0 * vE1, es1 = f1 * vE1, es2 = f2 * vE1; \
+    PGR_KEEP6(a31, a32, a41, a42, a51, a52); PGR_KEEP2(a61, a62);                                    \
+    PGR_KEEP6(bs0, bs1, bs2, es0, es1, es2);                                                         \
     PGR_SB();                                                                                        \
     C.rhs_f(ft2, wr[0], ps2, k20, k21, k22, cs);                                                     \
     PGR_STAMP(4);                                                                                    \
@@ -817,6 +881,7 @@ struct Dense {
     a41 = a41 + k21 * vA42; a42 = a42 + k22 * vA42;                                                    \
     a51 = a51 + k21 * vA52; a52 = a52 + k22 * vA52;                                                    \
     a61 = a61 + k21 * vA62; a62 = a62 + k22 * vA62;                                                    \
+    PGR_KEEP6(a41, a42, a51, a52, a61, a62);                                                         \
     PGR_SB();                                                                                        \
     C.rhs_f(ft3, wr[1], ps3, k30, k31, k32, cs);                                                     \
     PGR_STAMP(6);                                                                                    \
@@ -829,6 +894,7 @@ struct Dense {
     a61 = a61 + k31 * vA63; a62 = a62 + k32 * vA63;                                                    \
     bs0 = bs0 + k30 * vB3; bs1 = bs1 + k31 * vB3; bs2 = bs2 + k32 * vB3;                                \
     es0 = es0 + k30 * vE3; es1 = es1 + k31 * vE3; es2 = es2 + k32 * vE3;                                \
+    PGR_KEEP6(bs0, bs1, bs2, es0, es1, es2); PGR_KEEP2(a51, a52); PGR_KEEP2(a61, a62);               \
     PGR_SB();                                                                                        \
     C.rhs_f(ft4, wr[2], ps4, k40, k41, k42, cs);                                                     \
     PGR_STAMP(8);                                                                                    \
@@ -840,6 +906,7 @@ struct Dense {
     a61 = a61 + k41 * vA64; a62 = a62 + k42 * vA64;                                                    \
     bs0 = bs0 + k40 * vB4; bs1 = bs1 + k41 * vB4; bs2 = bs2 + k42 * vB4;                                \
     es0 = es0 + k40 * vE4; es1 = es1 + k41 * vE4; es2 = es2 + k42 * vE4;                                \
+    PGR_KEEP6(bs0, bs1, bs2, es0, es1, es2); PGR_KEEP2(a61, a62);                                    \
     PGR_SB();                                                                                        \
     C.rhs_f(ft5, wr[3], ps5, k50, k51, k52, cs);                                                     \
     PGR_STAMP(10);                                                                                   \
@@ -850,6 +917,7 @@ struct Dense {
     PGR_SB();                                                                                        \
     bs0 = bs0 + k50 * vB5; bs1 = bs1 + k51 * vB5; bs2 = bs2 + k52 * vB5;                                \
     es0 = es0 + k50 * vE5; es1 = es1 + k51 * vE5; es2 = es2 + k52 * vE5;                                \
+    PGR_KEEP6(bs0, bs1, bs2, es0, es1, es2);                                                         \
     PGR_SB();                                                                                        \
     C.rhs_f(ft6, wr[4], ps6, k60, k61, k62, cs);                                                     \
     PGR_STAMP(12);                                                                                   \
@@ -863,6 +931,7 @@ struct Dense {
     bs0 = bs0 + k60 * vB6;                                                                            \
     const double n0 = y0 + (H_) * bs0;                                                               \
     es0 = es0 + k60 * vE6; es1 = es1 + k61 * vE6; es2 = es2 + k62 * vE6;                                \
+    { double n0k_ = n0; PGR_KEEP2(n0k_, es0); PGR_KEEP2(es1, es2); }                                 \
     PGR_SB();                                                                                        \
     double c_new;                                                                                    \
     C.rhs_f(ft7, wr[4], n2, k70, k71, k72, c_new);                                                   \

@@ -33,7 +33,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     // literals) into constant re-materialisation + SGPR spills inside the step loop
     const EnvDev& env = *env_p;
     extern __shared__ double2 lds_tab[];
-    // LDS layout: [{c, cp}[nz] when LDS_TAB][zin[nz] when ZM >= 2, zbucket[zb_B] when ZM == 2][bathymetry]
+    // LDS layout: [{c, cp}[nz] when LDS_TAB][zin[nz] when ZM is 2, 3 or 5, zbucket[zb_B] when ZM == 2][bathymetry]
     double* const lds_after_tab = (double*)(lds_tab + (LDS_TAB ? env.nz : 0));
     double* const lds_z = lds_after_tab;
     unsigned short* const lds_zb = (unsigned short*)(lds_z + env.nz);
@@ -41,7 +41,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
         // stage the single depth profile {c, cp}[nz] into LDS (coalesced 16 B per lane)
         for (int j = threadIdx.x; j < env.nz; j += blockDim.x) lds_tab[j] = env.tab[j];
     }
-    if (ZM == 2 || ZM == 3) {
+    if (ZM == 2 || ZM == 3 || ZM == 5) {
         for (int j = threadIdx.x; j < env.nz; j += blockDim.x) lds_z[j] = env.zin[j];
         if (ZM == 2) for (int j = threadIdx.x; j < env.zb_B; j += blockDim.x) lds_zb[j] = env.zbucket[j];
     }
@@ -190,6 +190,16 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
         PGR_PIN(SQRT3); PGR_PIN(INV_SQRT3);
         PGR_PIN(POW_FIFTH); PGR_PIN(POW_KLN2);
 #undef PGR_PIN
+    }
+    // ZM == 5: a Horner step whose multiplier AND addend are wave-uniform costs a v_mov (one scalar operand per
+    // VALU instruction): the addend of the first step of the index cubic and of the seed quadratic sit in VGPRs
+    // (6 look-ups per attempt use them)
+#ifndef PGR_PIN_ZC
+#define PGR_PIN_ZC 1
+#endif
+    if (ZM == 5 && PGR_PIN_ZC) {
+        asm volatile("" : "+v"(C.h_zc_g2));
+        asm volatile("" : "+v"(C.h_zc_s1));
     }
     // One trip = one step attempt of every stepping lane, THEN the gate that decides whether the
     // wave services its parked lanes.  (The first trip only runs the gate: every lane starts with

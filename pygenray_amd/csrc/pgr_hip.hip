@@ -301,7 +301,7 @@ extern "C" int pgr_env_set_option(pgr_env* env, int what, int a, int b)
         env->waves_per_block = a;
         return 0;
     case PGR_OPT_DEPTH_SEARCH:
-        if (a < 0 || a > 2) return fail("depth search: 0 = automatic, 1 = binary search, 2 = bucket table (no index polynomial)");
+        if (a < 0 || a > 3) return fail("depth search: 0 = automatic, 1 = binary search, 2 = bucket table, 3 = quadratic estimate + three nodes (no cubic)");
         env->depth_search = a;
         return 0;
     case PGR_OPT_PARK:
@@ -371,6 +371,101 @@ static bool build_notaknot(const double* x, const double* y, int64_t n, std::vec
         pp[4 * i + 3] = (b[i] + b[i + 1] - 2 * sl[i]) / (dx[i] * dx[i]);
     }
     return true;
+}
+
+
+// Least-squares polynomial of degree `deg` (<= 3) through (x_k, y_k), x normalised to [0, 1] by the caller:
+// normal equations in long double, Gaussian elimination with partial pivoting.  c[0..deg]; false if singular.
+static bool polyfit_ld(const std::vector<long double>& x, const std::vector<long double>& y, int deg, long double* c)
+{
+    const int m = deg + 1;
+    long double A[4][5] = {};
+    for (size_t k = 0; k < x.size(); k++) {
+        long double p[7];
+        p[0] = 1;
+        for (int q = 1; q <= 2 * deg; q++) p[q] = p[q - 1] * x[k];
+        for (int r = 0; r < m; r++) {
+            for (int q = 0; q < m; q++) A[r][q] += p[r + q];
+            A[r][m] += p[r] * y[k];
+        }
+    }
+    for (int col = 0; col < m; col++) {
+        int piv = col;
+        for (int r = col + 1; r < m; r++) if (fabsl(A[r][col]) > fabsl(A[piv][col])) piv = r;
+        if (A[piv][col] == 0) return false;
+        for (int q = 0; q <= m; q++) { long double t = A[col][q]; A[col][q] = A[piv][q]; A[piv][q] = t; }
+        for (int r = 0; r < m; r++) {
+            if (r == col) continue;
+            const long double f = A[r][col] / A[col][col];
+            for (int q = col; q <= m; q++) A[r][q] -= f * A[col][q];
+        }
+    }
+    for (int r = 0; r < m; r++) c[r] = A[r][m] / A[r][r];
+    return true;
+}
+
+// EnvDev::z_cubic: a cubic in z that estimates the node index of a smooth non-uniform depth grid to a small
+// fraction of a cell, and a quadratic in the cell index for the reciprocal of the cell width.  Everything the
+// device relies on is VERIFIED here, with the device's own operations (fma Horner forms), for every node / cell;
+// a grid that fails any check keeps the three-node search (z_quad / z_bucket) or the binary search.
+static void fit_cubic_index(const double* zin, int64_t nz, EnvDev& d)
+{
+    d.z_cubic = 0;
+    d.zc_g0 = d.zc_g1 = d.zc_g2 = d.zc_g3 = d.zc_s0 = d.zc_s1 = d.zc_s2 = 0.0;
+    if (d.z_uniform || nz < 8 || !(zin[nz - 1] > zin[0])) return;
+    const long double z0 = zin[0], span = (long double)zin[nz - 1] - z0;
+    std::vector<long double> u((size_t)nz), jj((size_t)nz);
+    for (int64_t j = 0; j < nz; j++) { u[(size_t)j] = ((long double)zin[j] - z0) / span; jj[(size_t)j] = (long double)j; }
+    long double c[4];
+    if (!polyfit_ld(u, jj, 3, c)) return;
+    // t(z) = sum_k c_k ((z - z0) / span)^k expanded in powers of z
+    const long double a = 1 / span, b = -z0 / span;   // u = a z + b
+    long double g[4];
+    g[0] = c[0] + b * (c[1] + b * (c[2] + b * c[3]));
+    g[1] = a * (c[1] + b * (2 * c[2] + 3 * b * c[3]));
+    g[2] = a * a * (c[2] + 3 * b * c[3]);
+    g[3] = a * a * a * c[3];
+    double G[4] = {(double)g[0], (double)g[1], (double)g[2], (double)g[3]};
+    auto idx = [&](double z) { return std::fma(z, std::fma(z, std::fma(z, G[3], G[2]), G[1]), G[0]); };
+    // the estimate at the nodes: bias it down by its worst error (plus a margin that dwarfs the rounding of the
+    // Horner form, ~1e-12 cells) so that t(zin[j]) <= j; with t increasing, a z of cell j then has
+    // j - 1 <= t(z) < j + 1
+    double worst = 0;
+    for (int64_t j = 0; j < nz; j++) worst = std::fmax(worst, std::fabs(idx(zin[j]) - (double)j));
+    if (!(worst <= 0.01)) return;
+    const double bias = 2 * worst + 1e-7;
+    G[0] -= bias;
+    for (int64_t j = 0; j < nz; j++) {
+        const double t = idx(zin[j]);
+        if (!(t <= (double)j - 0.5e-7) || !(t >= (double)j - 0.05)) return;
+        // t'(z) > 0 at every node and at the vertex of t' (a parabola: its extremum) when that lies inside the grid
+        const double dt = G[1] + zin[j] * (2 * G[2] + 3 * zin[j] * G[3]);
+        if (!(dt > 0)) return;
+    }
+    if (G[3] != 0) {
+        const double zv = -G[2] / (3 * G[3]);
+        if (zv > zin[0] && zv < zin[nz - 1] && !(G[1] + zv * (2 * G[2] + 3 * zv * G[3]) > 0)) return;
+    }
+    // reciprocal cell width as a quadratic in the cell index
+    std::vector<long double> ju((size_t)nz - 1), inv((size_t)nz - 1);
+    const long double jn = (long double)(nz - 2 > 0 ? nz - 2 : 1);
+    for (int64_t j = 0; j + 1 < nz; j++) {
+        const double den = zin[j + 1] - zin[j];
+        if (!(den > 0)) return;
+        ju[(size_t)j] = (long double)j / jn;
+        inv[(size_t)j] = 1 / (long double)den;
+    }
+    long double sc[3];
+    if (!polyfit_ld(ju, inv, 2, sc)) return;
+    const double S[3] = {(double)sc[0], (double)(sc[1] / jn), (double)(sc[2] / (jn * jn))};
+    for (int64_t j = 0; j + 1 < nz; j++) {
+        const double den = zin[j + 1] - zin[j], jf = (double)j;
+        const double y = std::fma(jf, std::fma(jf, S[2], S[1]), S[0]);
+        if (!(std::fabs(std::fma(-den, y, 1.0)) <= 1e-8)) return;
+    }
+    d.z_cubic = 1;
+    d.zc_g0 = G[0]; d.zc_g1 = G[1]; d.zc_g2 = G[2]; d.zc_g3 = G[3];
+    d.zc_s0 = S[0]; d.zc_s1 = S[1]; d.zc_s2 = S[2];
 }
 
 template <class T>
@@ -543,6 +638,7 @@ extern "C" int pgr_env_create(pgr_env** out, int device, const double* cin, cons
             if (ok) { d.z_quad = 1; d.zq_c0 = c0; d.zq_c1 = c1; d.zq_c2 = c2; d.zq_inv_span = inv_span; d.zb_z0 = zin[0]; }
         }
     }
+    fit_cubic_index(zin, nz, d);
     if (upload(e, &e->d, 1, &e->d_dev)) { pgr_env_destroy(e); return -1; }
     *out = e;
     return 0;
@@ -557,6 +653,9 @@ extern "C" int pgr_env_query(const pgr_env* env, int what)
     case 2: return env->d.r_uniform;
     case 3: return env->lds_path;
     case 4: return env->device;
+    case 5: return env->d.z_cubic;
+    case 6: return env->d.z_quad;
+    case 7: return env->d.z_bucket;
     default: return fail("pgr_env_query: unknown property");
     }
 }
@@ -653,7 +752,11 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
     const size_t zq_bytes = (size_t)D.nz * sizeof(double);
     size_t zx_bytes = 0;  // LDS taken by the depth search of the chosen variant
     if (!D.z_simple && env->depth_search != 1) {
-        if (D.z_quad && env->depth_search == 0) {
+        if (D.z_cubic && env->depth_search == 0) {
+            if (env->range_indep && tab_bytes + zq_bytes <= env->max_lds) { lds_tab = true; zm = 5; zx_bytes = zq_bytes; }
+            else if (zq_bytes <= env->max_lds) { lds_tab = false; zm = 5; zx_bytes = zq_bytes; }
+        }
+        if (zm == 0 && D.z_quad && (env->depth_search == 0 || env->depth_search == 3)) {
             if (env->range_indep && tab_bytes + zq_bytes <= env->max_lds) { lds_tab = true; zm = 3; zx_bytes = zq_bytes; }
             else if (zq_bytes <= env->max_lds) { lds_tab = false; zm = 3; zx_bytes = zq_bytes; }
         }
@@ -715,10 +818,12 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
     } while (0)
     if (lds_tab) {
         if (zm == 1) PGR_LAUNCH(true, 1); else if (zm == 2) PGR_LAUNCH(true, 2);
-        else if (zm == 3) PGR_LAUNCH(true, 3); else if (zm == 4) PGR_LAUNCH(true, 4); else PGR_LAUNCH(true, 0);
+        else if (zm == 3) PGR_LAUNCH(true, 3); else if (zm == 4) PGR_LAUNCH(true, 4); else if (zm == 5) PGR_LAUNCH(true, 5);
+        else PGR_LAUNCH(true, 0);
     } else {
         if (zm == 1) PGR_LAUNCH(false, 1); else if (zm == 2) PGR_LAUNCH(false, 2);
-        else if (zm == 3) PGR_LAUNCH(false, 3); else if (zm == 4) PGR_LAUNCH(false, 4); else PGR_LAUNCH(false, 0);
+        else if (zm == 3) PGR_LAUNCH(false, 3); else if (zm == 4) PGR_LAUNCH(false, 4); else if (zm == 5) PGR_LAUNCH(false, 5);
+        else PGR_LAUNCH(false, 0);
     }
 #undef PGR_LAUNCH
 #undef PGR_LAUNCH1

@@ -21,6 +21,8 @@ env = pr.OceanEnvironment2D(ssp, bathy, flat_earth_transform=True)
 for fe in (False, True):
     arrs = _unpack_envi(env, flatearth=fe)
     h = _lib.EnvHandle(*arrs)
+    if os.environ.get('PGR_DEPTH_SEARCH'):   # 3 = quadratic estimate + three nodes (round 2's kernel), 2 = bucket table, 1 = binary search
+        h.set_option("depth_search", int(os.environ['PGR_DEPTH_SEARCH']))
     y0 = fan_y0(arrs, 1000.0, 0.0, -np.linspace(-20, 20, n))
     for save in (False, True):
         fan = DeviceFan(h, y0, 0.0, rmax, 1001, save=save, sample_major=True)

@@ -68,8 +68,15 @@ def kind(t):
 
 
 # the step loop: blocks with ds_read_b128 (LDS table) or global_load_dwordx4 (HBM table) inside a cycle
-hot = [i for i, b_ in enumerate(blocks) if sum(1 for t in b_[1] if t.startswith(("ds_read_b128", "global_load_dwordx4"))) >= 4]
-print("blocks with >= 4 table reads:", [(blocks[i][0], len(blocks[i][1])) for i in hot])
+need = 4
+hot = [i for i, b_ in enumerate(blocks) if sum(1 for t in b_[1] if t.startswith(("ds_read_b128", "global_load_dwordx4"))) >= need]
+if not hot:
+    # (kernels whose look-up ends in a rarely taken block -- ZM = 5 -- have one table read pair per block:
+    # start from the first such block that sits in a loop, i.e. the attempt's first stage)
+    need = 2
+    hot = [i for i, b_ in enumerate(blocks) if sum(1 for t in b_[1] if t.startswith(("ds_read_b128", "global_load_dwordx4"))) >= need
+           and sum(1 for t in b_[1] if t.startswith("v_")) >= 60][:1]
+print(f"blocks with >= {need} table reads:", [(blocks[i][0], len(blocks[i][1])) for i in hot])
 for i in hot[:2]:
     # walk the fall-through / branch chain from this block until we come back to it
     seen, order, j = set(), [], i

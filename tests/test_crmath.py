@@ -17,7 +17,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 @pytest.fixture(scope="module")
 def crh(tmp_path_factory):
     so = str(tmp_path_factory.mktemp("crmath") / "libcrmath_host.so")
-    subprocess.check_call(["gcc", "-O2", "-std=gnu99", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+    # CRMATH_SANITIZE=1 (tests/test_sanitizers.py, in a python started with libasan preloaded): the same text under
+    # AddressSanitizer + UBSan
+    san = (["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"]
+           if os.environ.get("CRMATH_SANITIZE") == "1" else ["-O2"])
+    subprocess.check_call(["gcc"] + san + ["-std=gnu99", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
                            "-fopenmp", "-Wno-unknown-pragmas", "-o", so, os.path.join(HERE, "crmath_host.c"), "-lm"])
     L = ctypes.CDLL(so)
     dp = ctypes.POINTER(ctypes.c_double)
@@ -30,7 +34,7 @@ def crh(tmp_path_factory):
     return ev
 
 
-N = 2_000_000
+N = int(os.environ.get("CRMATH_N", 2_000_000))
 
 
 def test_pow_of_the_step_controller_is_correctly_rounded(crh):

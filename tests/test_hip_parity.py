@@ -535,6 +535,70 @@ def test_full_size_config1_properties(lib):
     assert 1.2e8 < total < 1.7e8
 
 
+def _subset(out, sub, n):
+    return {k: (v[sub] if isinstance(v, np.ndarray) and v.shape[:1] == (n,) else v) for k, v in out.items()}
+
+
+def test_full_size_config2_properties(lib):
+    """BASELINE configs[2] at full size (range-dependent c(r, z): sofar axis + 2e-4 r over 101 columns, 1e5 rays,
+    1000 km; the tables stay in HBM / L2): every 100th ray against the oracle BIT FOR BIT -- with trajectories in
+    SciPy's sample order, with the default sample form, and end state only (three different kernel instances) --
+    and the three runs agree with each other on every one of the 1e5 rays."""
+    arrs = munk_arrays(1000e3, nr=101, sofar_slope=2e-4)
+    n = 100_000
+    y0 = y0_for(oracle, arrs, 1000.0, 0.0, -np.linspace(-20, 20, n))
+    env = lib.EnvHandle(*arrs)
+    assert not env.lds_path and not env.range_independent
+    a = env.shoot_fan(y0, 0.0, 1000e3, 101, exact_samples=True)
+    b = env.shoot_fan(y0, 0.0, 1000e3, 101)
+    c = env.shoot_fan(y0, 0.0, 1000e3, 101, save=False)
+    for k in ("end", "n_steps", "n_rej", "n_bott", "n_surf", "status"):
+        assert np.array_equal(a[k], b[k], equal_nan=True) and np.array_equal(a[k], c[k], equal_nan=True), k
+    sub = np.arange(0, n, 100)
+    o = oracle.shoot_fan(*arrs, y0[sub], 0.0, 1000e3, 101, math=oracle.MATH_CR)
+    st = assert_bit_parity(_subset(a, sub, n), o, label="config2, every 100th ray, SciPy sample order")
+    assert_bit_parity(_subset(b, sub, n), o, label="config2, every 100th ray, default samples", samples=False)
+    assert st["n"] > 980 and (o["n_bott"] + o["n_surf"] > 0).sum() > 250
+    ok = a["status"] == 0
+    assert 0.99 < ok.mean() < 1.0 and 1.2e8 < int(a["n_steps"][ok].sum()) < 1.7e8
+    env.close()
+
+
+def test_full_size_default_flat_earth_environment(lib):
+    """The reference's DEFAULT path at size: OceanEnvironment2D() (Munk profile on arange(0, 6000, 1), 4500 -> 4900 m
+    slope, flat_earth_transform=True: a smoothly NON-uniform zin -> the cubic-index depth look-up, kernel ZM = 5)
+    and shoot_rays(..., flatearth=True) with 1e5 launch angles over its 100 km.  Every 100th ray against the
+    oracle (which finds the depth cell by binary search, as np.searchsorted does) BIT FOR BIT, end state and all
+    samples; and the same fan through the three-node search of round 2 and through the binary search on the device:
+    equal on every ray."""
+    import pygenray_amd as pr
+    env_obj = pr.OceanEnvironment2D()
+    arrs = pr._unpack_envi(env_obj, flatearth=True)
+    assert not np.allclose(np.diff(arrs[3]), 1.0, rtol=0, atol=1e-9)      # the transformed grid is not uniform
+    n = 100_000
+    theta = np.linspace(-20, 20, n)
+    y0 = y0_for(oracle, arrs, 1000.0, 0.0, -theta)
+    env = lib.EnvHandle(*arrs)
+    assert env.query(5) == 1 and env.lds_path                            # cubic index estimate verified by the host
+    a = env.shoot_fan(y0, 0.0, 100e3, 101, exact_samples=True)
+    sub = np.arange(0, n, 100)
+    o = oracle.shoot_fan(*arrs, y0[sub], 0.0, 100e3, 101, math=oracle.MATH_CR)
+    st = assert_bit_parity(_subset(a, sub, n), o, label="default flat-earth environment, every 100th ray")
+    assert st["n"] > 900 and (o["n_bott"] + o["n_surf"] > 0).sum() > 200
+    for mode in (3, 2, 1):   # quadratic estimate + three nodes, bucket table, binary search
+        env.set_option("depth_search", mode)
+        b = env.shoot_fan(y0, 0.0, 100e3, 101, exact_samples=True)
+        for k in ("T", "z", "p", "end", "n_steps", "n_rej", "n_bott", "n_surf", "status"):
+            assert np.array_equal(a[k], b[k], equal_nan=True), (mode, k)
+    env.close()
+    # ... and through the drop-in API with the reference's default arguments (flatearth=True)
+    fan = pr.shoot_rays(1000.0, 0.0, theta, 100e3, 101, env_obj, debug=False)
+    keep = a["status"] == 0
+    assert len(fan) == int(keep.sum())
+    assert np.array_equal(fan.ts[:, -1], a["end"][keep, 0]) and np.array_equal(-fan.zs[:, -1], a["end"][keep, 1])
+    assert np.array_equal(fan.n_botts, a["n_bott"][keep])
+
+
 def test_arithmetic_building_blocks(lib):
     """The kernel's divide / sqrt expansions must be correctly rounded on the operand ranges that
     occur (they replace the compiler's IEEE expansions), 10*ulp(t) exact, and the three libm
@@ -833,7 +897,7 @@ def test_config3_eigenray_search_on_the_1e6_angle_fan(lib):
     assert np.array_equal(o["status"] == 0, alive[sub])
     ok = o["status"] == 0
     same = (fan.ts[pos[sub][ok], -1] == o["T"][ok, -1]) & (-fan.zs[pos[sub][ok], -1] == o["z"][ok, -1])
-    assert same.mean() >= 0.999, same.mean()
+    assert same.all(), (int((~same).sum()), int(same.size))   # every sampled ray bit-identical
     assert np.array_equal(fan.n_botts[pos[sub][ok]], o["n_bott"][ok]) and np.array_equal(fan.n_surfs[pos[sub][ok]], o["n_surf"][ok])
     # (ii) the reference's rays on three windows of the grid
     for j in range(3):
@@ -904,7 +968,7 @@ def test_config4_end_records_and_arrival_time_histogram_of_1e6_rays(lib):
     o = oracle.shoot_fan(*arrs, y0[sub], 0.0, 1000e3, 2, math=oracle.MATH_CR)
     okk = o["status"] == 0
     assert np.array_equal(okk, st[sub] == 0)
-    assert np.mean(T[sub][okk] == o["T"][okk, -1]) >= 0.995
+    assert np.all(T[sub][okk] == o["T"][okk, -1]), int(np.sum(T[sub][okk] != o["T"][okk, -1]))
     env.close()
 
 
@@ -988,4 +1052,4 @@ def test_random_environments_are_bit_identical_to_the_oracle(lib):
                              terminate_backwards=kw["terminate_backwards"])
         st = assert_bit_parity(g, o, label=f"seed {seed}: {desc}")
         n_rays += st["n"]; n_odd += st["odd"]
-    assert n_rays > 2000 and n_odd <= 2
+    assert n_rays > 2000 and n_odd == 0, (n_rays, n_odd)
