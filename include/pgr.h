@@ -98,7 +98,8 @@ void pgr_env_destroy(pgr_env* env);
 
 /* Properties the kernel selection depends on (for tests / diagnostics):
  * what = 0: tables range independent (all rows bitwise equal) ; 1: zin exactly uniform ;
- *        2: rin exactly uniform ; 3: LDS-resident table path selected ; 4: device index. */
+ *        2: rin exactly uniform ; 3: LDS-resident table path selected ; 4: device index ;
+ *        5 / 6 / 7: zin qualifies for the cubic index estimate / the quadratic one / the bin table. */
 int pgr_env_query(const pgr_env* env, int what);
 
 /* Shoot N rays: batched _shoot_ray_array + _interpolate_ray (REF/launch_rays.py:325-484,
@@ -169,21 +170,30 @@ int pgr_arrival_histogram_device(int device, const double* t_end, int64_t t_stri
 /* Tuning options of ONE environment (per-ray results never depend on them; there is no process-wide
  * state: host threads that drive different GPUs hold different environments).
  *   PGR_OPT_WAVES_PER_BLOCK  a = waves (of 64 rays) per workgroup, 0 = automatic
- *   PGR_OPT_DEPTH_SEARCH     depth-cell search for a non-uniform zin: a = 0 (default) from LDS -- the cell
- *                            of z is j0 or j0 + 1 with j0 = floor(g(z) - 0.5) from a quadratic index
- *                            estimate g when zin is smooth enough (the flat-earth grid is), else j0 =
+ *   PGR_OPT_DEPTH_SEARCH     depth-cell search for a non-uniform zin: a = 0 (default) from LDS -- when a cubic
+ *                            in z estimates the node index to a small fraction of a cell (the flat-earth
+ *                            transform of a uniform grid: 1.5e-8 cells), the cell is trunc(t(z)) or, rarely,
+ *                            the next one, and two nodes are read; else the cell is j0 or j0 + 1 with j0 =
+ *                            floor(g(z) - 0.5) from a quadratic estimate g (three nodes read), else j0 =
  *                            bucket[floor((z - z0)/w)] from a bin table; a = 1 always the binary search of
- *                            np.searchsorted (REF/integration_processes.py:152-157); a = 2 the bin table
- *                            even when the quadratic would do.  Tests compare the three.
+ *                            np.searchsorted (REF/integration_processes.py:152-157); a = 2 the bin table;
+ *                            a = 3 the quadratic estimate (no cubic).  Tests compare the four.
  *   PGR_OPT_PARK             bounce-service batching: a wave services its parked (bounced) lanes when `a`
  *                            of them wait or the oldest waited `b` step attempts (default 64, 10)
  *   PGR_OPT_PLACEMENT        cost-aware wave scheduling for fans of 1-2 waves per SIMD: a = 2 (default) the
  *                            costliest waves get a SIMD to themselves / are paired with the cheapest, plus
- *                            issue priorities by cost quartile; 1 = priorities only; 0 = strided deal */
+ *                            issue priorities by cost quartile; 1 = priorities only; 0 = strided deal
+ *   PGR_OPT_SAMPLE_RING      (experiment; only in a library built with -DPGR_SAMPLE_RING=1, an error otherwise)
+ *                            kernels whose table lives in HBM / L2 and that save trajectories: a = 1 the
+ *                            integrating waves drop their samples into an LDS ring and the workgroup's last
+ *                            wave writes complete 512-byte rows; a = 0 every lane stores its own samples.
+ *                            b & 255 = ring rows per wave (0 = automatic), b >> 8 = idle sleep of the writer.
+ *                            Measured slower than the direct stores; not in the product. */
 #define PGR_OPT_WAVES_PER_BLOCK 0
 #define PGR_OPT_DEPTH_SEARCH 1
 #define PGR_OPT_PARK 2
 #define PGR_OPT_PLACEMENT 3
+#define PGR_OPT_SAMPLE_RING 4
 int pgr_env_set_option(pgr_env* env, int what, int a, int b);
 
 /* Unit-level device entry points (for parity tests of a1-a8, REF/integration_processes.py):

@@ -88,6 +88,11 @@ struct FanArgs {
     int save_formula;  // r_save[j] == j*save_step + x0 bitwise (host verified)
     int park_lanes, park_trips;  // service batching thresholds
     int bathy_lds_off;    // byte offset of the LDS copy of {depth_ranges[nb], depths[nb]}, or -1 (read from HBM)
+    // HBM-table kernels that save trajectories: byte offset of the LDS sample ring and its rows per compute wave
+    // (a power of two; 0 = no ring, samples are stored directly).  With a ring the workgroup's LAST wave is the
+    // writer wave (pgr_fan_kernel.h) and integrates no rays.
+    int ring_lds_off, ring_rows;
+    int ring_sleep;       // the idle writer polls every ring_sleep x 1024 clocks
     const int* wave_map;  // [gridDim.x * waves_per_block] global wave of each slot, -1 = empty; null = strided deal
     int64_t max_steps;
     uint32_t flags;

@@ -53,17 +53,121 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
             lds_bx[env.nb + j] = env.depths[j];
         }
     }
+    // ---- the sample ring (HBM-table kernels that save trajectories) ----
+    // On gfx950 vector loads and stores retire in issue order through ONE counter (vmcnt), so in a kernel whose
+    // table reads are global loads every wait for a table read also waits for the sample stores issued before
+    // it -- and a wave's 64 rays own a given sample row in different trips, so those stores are partial lines,
+    // slow to retire and 2.2x amplified on the way to HBM (profiles/r02_config2_counters.json).  Here the
+    // integrating waves never store a sample to global memory: a lane drops (T, z, p) of sample j into its
+    // wave's LDS ring (row j mod R; ds_write does not count in vmcnt) and publishes its next sample index; the
+    // workgroup's last wave -- the WRITER, which integrates nothing and loads nothing from global memory --
+    // sends row j out as three full 512-byte stores once no lane of that wave can write it any more (every
+    // running lane has published jnext >= j + 2: a lane's later writes, a re-sample after a bounce included,
+    // Q5, have index >= jnext - 1).  A lane that runs more than R rows ahead of its wave's slowest lane stores
+    // that sample directly (its ring entry keeps the sentinel and the writer skips it).
+    // MEASURED (round 3, configs[2] with trajectories, one box): direct stores 7.0 ms; this ring 7.5 ms (16 rows),
+    // 7.7 / 7.9 ms with 8 / 4 rows; the ring with a writer that throws the rows away -- no global store at all
+    // from any wave -- 7.4 ms against 5.9 ms end state only.  The stores are not what the trajectory kernel waits
+    // for, and the ring's bookkeeping plus the writer's share of one SIMD cost more than it saves: it is NOT
+    // compiled into the product (-DPGR_SAMPLE_RING=1 builds it; results are bit-identical either way,
+    // scripts/regress.py).
+#ifndef PGR_SAMPLE_RING
+#define PGR_SAMPLE_RING 0
+#endif
+    constexpr bool RINGK = PGR_SAMPLE_RING && !LDS_TAB && SAVE != 0;
+    const int wv = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
+    const int ring_R = RINGK ? a.ring_rows : 0;
+    const int n_cw = (int)(blockDim.x >> 6) - (ring_R > 0 ? 1 : 0);   // integrating waves of this workgroup
+    // (explicit LDS pointers: a volatile access through a generic pointer is a flat_load / flat_store, which counts
+    // in vmcnt like any global access -- the very coupling the ring is there to remove)
+    typedef volatile int __attribute__((address_space(3))) * LdsIntP;
+    typedef volatile double __attribute__((address_space(3))) * LdsDblP;
+    typedef __attribute__((address_space(3))) char* LdsCharP;
+    const LdsIntP ring_pub = (LdsIntP)((LdsCharP)(char*)lds_tab + (RINGK ? a.ring_lds_off : 0));  // [n_cw][64] next sample index
+    const LdsIntP ring_base = ring_pub + n_cw * 64;            // [16] first row of each wave still in its ring
+    const LdsIntP ring_done = ring_base + 16;                  // [16] wave's rows all written out
+    const LdsDblP ring_data = (LdsDblP)(ring_base + 64);       // [n_cw][R][3][64]
+    const unsigned long long RING_EMPTY = 0x7ff8dead5a5a0001ULL;     // a NaN no arithmetic produces
+    if (ring_R > 0) {
+        for (int k = threadIdx.x; k < n_cw * 64; k += blockDim.x) ring_pub[k] = 0;
+        for (int k = threadIdx.x; k < 64; k += blockDim.x) ring_base[k] = 0;   // (base and done)
+        for (int k = threadIdx.x; k < n_cw * ring_R * 192; k += blockDim.x)
+            ring_data[k] = __longlong_as_double((long long)RING_EMPTY);
+    }
     __syncthreads();
+    if (ring_R > 0 && wv == n_cw) {
+        // =========================== WRITER wave ===========================
+        const int S1 = a.S - 1;   // rows 0 .. S-2 pass through the rings; the last column is the exact final state
+        unsigned done_mask = 0;
+        const unsigned all_done = (1u << n_cw) - 1u;
+        __builtin_amdgcn_s_setprio(0);
+        for (int spins = 0; done_mask != all_done && spins < (1 << 24);) {
+            bool progress = false;
+            for (int w = 0; w < n_cw; w++) {
+                if ((done_mask >> w) & 1u) continue;
+                const int pv = ring_pub[w * 64 + lane_id];
+                const int b = __builtin_amdgcn_readfirstlane(ring_base[w]);
+                const bool fin = ballot64(pv != 0x7fffffff) == 0;
+                // rows below `hi` are complete (row r: every lane has published jnext >= r + 2); those of them still
+                // in the ring window go out now, the rest were stored directly by their lanes
+                int hi = b;
+                if (fin) hi = S1;
+                else while (hi < S1 && ballot64(pv < hi + 2) == 0) hi++;
+                if (hi > b) {
+                    int64_t gw = (int64_t)w * gridDim.x + blockIdx.x;
+                    if (a.wave_map) {
+                        const int m = a.wave_map[blockIdx.x * n_cw + w];
+                        gw = (m < 0) ? -1 : (m & 0x0fffffff);
+                    }
+                    const int64_t wray = gw * 64 + lane_id;
+                    const int top = (hi < b + ring_R) ? hi : b + ring_R;
+                    for (int row = b; row < top; row++) {
+                        const LdsDblP e = ring_data + (((w * ring_R + (row & (ring_R - 1))) * 3) * 64 + lane_id);
+                        const double vt = e[0];
+                        if ((unsigned long long)__double_as_longlong(vt) != RING_EMPTY) {
+                            const double vz = e[64], vp = e[128];
+                            const int64_t o = wray * a.stride_ray + (int64_t)row * a.stride_smp;
+#ifdef PGR_RING_EXPERIMENT   // store policy of the writer: 0 streaming, 1 plain (write-back), 2 none at all (wrong results: timing only)
+                            if (((a.ring_sleep >> 8) & 3) == 1) { a.T[o] = vt; a.Z[o] = vz; a.P[o] = vp; }
+                            else if (((a.ring_sleep >> 8) & 3) == 0)
+#endif
+                            {
+                            __builtin_nontemporal_store(vt, a.T + o);
+                            __builtin_nontemporal_store(vz, a.Z + o);
+                            __builtin_nontemporal_store(vp, a.P + o);
+                            }
+                            e[0] = __longlong_as_double((long long)RING_EMPTY);
+                        }
+                    }
+                    ring_base[w] = hi;   // (behind the sentinel writes: the LDS serves one wave's operations in order)
+                    progress = true;
+                }
+                if (fin) {
+                    // this wave's rows are on their way: when they have reached the L2, tell the wave (its epilogue
+                    // overwrites the columns of dropped rays with NaN and must come after them)
+                    __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0) expcnt(0) lgkmcnt(0)
+                    ring_done[w] = 1;
+                    done_mask |= 1u << w;
+                    progress = true;
+                }
+            }
+            if (!progress) {
+                for (int k = 0; k < (a.ring_sleep & 255); k++) __builtin_amdgcn_s_sleep(16);   // 16 x 64 clocks each
+                spins++;
+            }
+        }
+        return;
+    }
     const Ctx<LDS_TAB, ZM> C(env, lds_tab, lds_z, lds_zb, lds_bx);
     C.declare_span(a.x0, a.x1);
     // waves are dealt to workgroups round-robin (wave w of block b = global wave w*grid + b):
     // neighbouring launch angles cost alike, so a strided deal balances the CUs
-    int64_t gwave = (int64_t)(threadIdx.x >> 6) * gridDim.x + blockIdx.x;
+    int64_t gwave = (int64_t)wv * gridDim.x + blockIdx.x;
     if (a.wave_map) {
         // cost-aware scheduling (pgr_wave_place): slot -> wave (-1 = slot left empty) and the
         // wave's issue priority in bits 28..29: the costlier wave of a SIMD's pair runs at its own
         // pace, the cheaper one fills the issue slots it leaves
-        int m = a.wave_map[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)];
+        int m = a.wave_map[blockIdx.x * n_cw + wv];
         gwave = (m < 0) ? -1 : (m & 0x0fffffff);
         int prio = __builtin_amdgcn_readfirstlane((m < 0) ? 0 : ((m >> 28) & 3));
         if (prio == 3) __builtin_amdgcn_s_setprio(3);
@@ -121,6 +225,34 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
 #define Tp (a.T + out_off)
 #define Zp (a.Z + out_off)
 #define Pp (a.P + out_off)
+    // one saved sample (T, z, p) of row j leaves the lane: into the wave's LDS ring when the kernel has one and the
+    // row lies inside its window [rbase, rbase + R) (rbase: the writer's count of rows already sent out, re-read
+    // once per trip; an old value only narrows the window), else straight to global memory -- streaming stores
+    // when the table lives in HBM / L2 (2.4 GB of samples per fan must not evict the table rows), plain ones with
+    // the LDS table (measured faster there)
+    int rbase = 0;
+    auto emit_sample = [&](int j, double vt, double vz, double vp) __attribute__((always_inline)) {
+        bool direct = true;
+        if (RINGK) {
+            const bool inr = (unsigned)(j - rbase) < (unsigned)ring_R;
+            direct = !inr;
+            if (inr) {
+                const LdsDblP e = ring_data + (((wv * ring_R + (j & (ring_R - 1))) * 3) * 64 + lane_id);
+                e[0] = vt; e[64] = vz; e[128] = vp;
+            }
+        }
+        if (!RINGK || __builtin_expect(ballot64(direct) != 0, 0)) {
+            if (direct) {
+                const int64_t o = (int64_t)j * a.stride_smp;
+                if (LDS_TAB) { Tp[o] = vt; Zp[o] = vz; Pp[o] = vp; }
+                else {
+                    __builtin_nontemporal_store(vt, &Tp[o]);
+                    __builtin_nontemporal_store(vz, &Zp[o]);
+                    __builtin_nontemporal_store(vp, &Pp[o]);
+                }
+            }
+        }
+    };
 
     // The 26 tableau coefficients of the stage sums live in VGPRs for the whole kernel (the kernel
     // needs ~155 of its 256 VGPRs otherwise): an fp64 literal cannot be an inline operand, so each use
@@ -213,6 +345,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
         do {
         trips++;
         PGR_STAMP(0);
+        if (RINGK && ring_R > 0) rbase = ring_base[wv];
         if (status == RUNNING && !parked && !need_init) {
             // ---- one attempt of RK45._step_impl, SCIPY/rk.py:111-176 ----
             // min_step = 10 ulp(t) <= 10 * 2^-52 max(|x0|, |x1|) =: min_step_bound for every t of the fan: a wave none
@@ -298,9 +431,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                             while (jnext < S - 1 && rnext <= t_new) {
                                 double o0, o1, o2;
                                 D.eval(t, y0, y1, y2, rnext, o0, o1, o2);
-                                Tp[(int64_t)jnext * a.stride_smp] = o0;
-                                Zp[(int64_t)jnext * a.stride_smp] = SGN(o1);
-                                Pp[(int64_t)jnext * a.stride_smp] = SGN(o2);
+                                emit_sample(jnext, o0, SGN(o1), SGN(o2));
                                 jnext++;
                                 rnext = G.at(jnext);
                             }
@@ -313,13 +444,6 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
 #define PGR_KSUM(k1, k3, k4, k5, k6, k7)                                                          \
     __builtin_fma(k1, b1, __builtin_fma(k3, b3, __builtin_fma(k4, b4, __builtin_fma(k5, b5,      \
                   __builtin_fma(k6, b6, (k7) * b7)))))
-// trajectory stores: with the table in HBM/L2 they are streaming (non-temporal) stores, so that
-// 2.4 GB of samples per fan do not evict the table rows from L2 (range-dependent fan with
-// trajectories 8.5 -> 7.7 ms); with the table in LDS plain stores are faster (5.9 vs 6.3 ms)
-#define PGR_SSTORE(v, p)                                                                          \
-    do {                                                                                          \
-        if (LDS_TAB) *(p) = (v); else __builtin_nontemporal_store((v), (p));                      \
-    } while (0)
 #define PGR_SAMPLE_LOOP(NEXT)                                                                     \
     while (jnext < S - 1 && rnext <= t_new) {                                                     \
         const double xi = (rnext - t) * inv_h, x2 = xi * xi;                                      \
@@ -329,9 +453,9 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
         const double b5 = x2 * __builtin_fma(xi, __builtin_fma(xi, vP53, vP52), vP51);               \
         const double b6 = x2 * __builtin_fma(xi, __builtin_fma(xi, vP63, vP62), vP61);               \
         const double b7 = x2 * __builtin_fma(xi, __builtin_fma(xi, vP73, vP72), vP71);               \
-        PGR_SSTORE(__builtin_fma(h, PGR_KSUM(f0, k30, k40, k50, k60, k70), y0), &Tp[(int64_t)jnext * a.stride_smp]); \
-        PGR_SSTORE(SGN(__builtin_fma(h, PGR_KSUM(f1, k31, k41, k51, k61, k71), y1)), &Zp[(int64_t)jnext * a.stride_smp]); \
-        PGR_SSTORE(SGN(__builtin_fma(h, PGR_KSUM(f2, k32, k42, k52, k62, k72), y2)), &Pp[(int64_t)jnext * a.stride_smp]); \
+        emit_sample(jnext, __builtin_fma(h, PGR_KSUM(f0, k30, k40, k50, k60, k70), y0),            \
+                    SGN(__builtin_fma(h, PGR_KSUM(f1, k31, k41, k51, k61, k71), y1)),               \
+                    SGN(__builtin_fma(h, PGR_KSUM(f2, k32, k42, k52, k62, k72), y2)));              \
         jnext++;                                                                                  \
         rnext = NEXT;                                                                             \
     }
@@ -342,7 +466,6 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                             if (SAVE == 1 || G.formula) { PGR_SAMPLE_LOOP(grid_at(G.x0, G.step, jnext)) }
                             else { PGR_SAMPLE_LOOP(G.r[jnext]) }
 #undef PGR_SAMPLE_LOOP
-#undef PGR_SSTORE
 #undef PGR_KSUM
                         }
                     }
@@ -358,6 +481,8 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
         }
         PGR_STAMP(19);
         run = (status == RUNNING);
+        // (behind this trip's ring writes: rows below jnext - 1 will not be written by this lane again)
+        if (RINGK && ring_R > 0) ring_pub[wv * 64 + lane_id] = run ? jnext : 0x7fffffff;
         pend = run && (parked || need_init);
         pm = ballot64(pend);
         } while (pm == 0 && ballot64(run) != 0);
@@ -383,6 +508,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                 asm volatile("" : "+s"(ks_p));
                 const FanArgs __attribute__((address_space(4))) & as = *(const FanArgs __attribute__((address_space(4))) *)(ks_p + 8);
                 const double svc_c_lo = es.c_lo, svc_c_hi = es.c_hi;
+                if (RINGK && ring_R > 0) rbase = ring_base[wv];
 #ifdef PGR_DBG_REPLAY
                 const unsigned long long dbg_s0 = __builtin_amdgcn_s_memtime();
                 unsigned long long dbg_s1 = dbg_s0, dbg_s4 = dbg_s0, dbg_s5 = dbg_s0, dbg_r0 = dbg_s0, dbg_r3 = dbg_s0;
@@ -685,9 +811,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                             while (jnext < S - 1 && rnext <= t_end) {
                                 double o0, o1, o2;
                                 D.eval(t, y0, y1, y2, rnext, o0, o1, o2);
-                                Tp[(int64_t)jnext * a.stride_smp] = o0;
-                                Zp[(int64_t)jnext * a.stride_smp] = SGN(o1);
-                                Pp[(int64_t)jnext * a.stride_smp] = SGN(o2);
+                                emit_sample(jnext, o0, SGN(o1), SGN(o2));
                                 jnext++;
                                 rnext = G.at(jnext);
                             }
@@ -795,6 +919,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                         rnext = G.at(jnext);
                     }
                 }
+                if (RINGK && ring_R > 0) ring_pub[wv * 64 + lane_id] = (status == RUNNING) ? jnext : 0x7fffffff;
 #ifdef PGR_DBG_REPLAY
                 {
                     const unsigned long long dbg_s6 = __builtin_amdgcn_s_memtime();
@@ -810,6 +935,14 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
         }
     } while (ballot64(status == RUNNING) != 0);
 
+    if (RINGK && ring_R > 0) {
+        // every lane is through: the writer sends out what is left of this wave's rows.  A wave with a dropped ray
+        // waits for that (its NaN columns below must land after the writer's rows; bounded, never a hang)
+        ring_pub[wv * 64 + lane_id] = 0x7fffffff;
+        if (ballot64(valid && status != PGR_RAY_OK) != 0) {
+            for (int spins = 0; ring_done[wv] == 0 && spins < (1 << 22); spins++) __builtin_amdgcn_s_sleep(8);
+        }
+    }
     if (valid) {
         bool ok = (status == PGR_RAY_OK);
         double nan = __longlong_as_double(0x7ff8000000000000LL);
