@@ -22,7 +22,9 @@ SURVEY.md 8(d)'s algorithmic bytes, `roofline_valu` against the fp64 VALU issue 
 bounds it; `cpu_baseline` is the reference's own call pattern (scipy.integrate.solve_ivp, RK45,
 4 terminal events, NumPy right-hand side: oracle/scipy_port.py -- the reference itself cannot
 travel to the GPU box) on all usable host cores, `cpu_baseline_c` the C/OpenMP oracle; `eigenray`
-the wall-clock of configs[3] (1e6-angle fan + regula-falsi refinement); rank 0 at N = 1 only.
+the wall-clock of configs[3] (1e6-angle fan + regula-falsi refinement); `legs` = the kernel instances users hit
+beside the headline one (default flat-earth grid, configs[2], 1e6 rays), a few passes each, and `lone_wave_ms` the
+64 steepest rays alone (the floor of the fan's kernel time); rank 0 at N = 1 only.
 """
 import argparse
 import json
@@ -37,6 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 RAYS_PER_GPU = 100_000
+BASELINE_METRIC = "ray-steps/sec (whole node), 1e5-ray Munk fan to 1000 km; eigenray wall-clock"   # BASELINE.json
 RANGE_M = 1000e3
 S_SAVE = 1001
 SOURCE_DEPTH = 1000.0
@@ -61,8 +64,12 @@ def parse_args(argv=None):
     ap.add_argument("--range-dependent", action="store_true",
                     help="BASELINE configs[2]: sofar axis sloping 2e-4 over 101 range columns (tables stay in HBM/L2); "
                          "not the headline workload")
+    ap.add_argument("--flat-earth", action="store_true",
+                    help="the configs[1] tables after OceanEnvironment2D's default flat-earth transform (non-uniform zin, "
+                         "kernel ZM = 5): what pr.shoot_rays(...) integrates with the reference's default arguments; not the headline workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eigenray", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="skip the extra kernel legs (flat-earth default grid, configs[2], 1e6 rays, lone wave)")
     ap.add_argument("--eigen-rays", type=int, default=1_000_000, help="fan size of the eigenray leg (configs[3])")
     ap.add_argument("--waves-per-block", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; tests rehearse with gloo)")
@@ -133,21 +140,32 @@ def cpu_baseline_c(arrs, n_rays=25000):
                       f"{cores} threads (cgroup CPU quota of the box)"}
 
 
-def _scipy_chunk(job):
+_POOL_ARRS = None
+
+
+def _pool_init(arrs):
+    """Pool initializer: the tables reach every worker ONCE (not pickled with each task inside the timed map)."""
+    global _POOL_ARRS
+    _POOL_ARRS = arrs
+    import oracle.scipy_port  # noqa: F401  (imports done before the clock starts)
+
+
+def _scipy_chunk(y0):
     """One pool task: a chunk of rays through the reference's solve_ivp call pattern."""
-    arrs, y0 = job
     from oracle import scipy_port
-    out = scipy_port.shoot_fan(*arrs, y0, 0.0, RANGE_M, S_SAVE)
+    out = scipy_port.shoot_fan(*_POOL_ARRS, y0, 0.0, RANGE_M, S_SAVE)
     return int(out["n_steps"].sum()), int((out["status"] == 0).sum())
 
 
 def cpu_baseline_scipy(arrs, seconds_budget=25.0):
     """the NumPy/SciPy call pattern of the reference -- solve_ivp(RK45, rtol 1e-9, atol
     1e-6, dense output, 4 terminal events, REF/launch_rays.py:670-679) restarted at every bounce, NumPy
-    right-hand side (un-jitted: the reference's numba decorator is not available here either) -- on ALL
-    usable host cores through a spawn pool, one chunk of rays per task (the reference's pool maps one
-    ray per task, REF/launch_rays.py:157-164), on a strided subset of the same 1e5-ray fan sized to the
-    time budget."""
+    right-hand side -- on ALL usable host cores through a spawn pool, one chunk of rays per task (the
+    reference's pool maps one ray per task, REF/launch_rays.py:157-164), on a strided subset of the same
+    1e5-ray fan sized to the time budget.  UN-JITTED: the reference compiles its right-hand side and event
+    functions with numba (REF/integration_processes.py:26), which this image does not have, so this
+    under-states a real pygenray install by the RHS share of a step (SciPy's per-step Python overhead,
+    ~100 us, remains either way); `cpu_baseline_c` is the compiled restatement of the same path."""
     import multiprocessing as mp
     from pygenray_amd.device_fan import fan_y0
     cores = host_cores()
@@ -157,23 +175,84 @@ def cpu_baseline_scipy(arrs, seconds_budget=25.0):
     theta = np.linspace(-20, 20, RAYS_PER_GPU)[::stride][:n_rays]
     y0 = fan_y0(arrs, SOURCE_DEPTH, 0.0, -theta)
     order = np.random.default_rng(0).permutation(len(y0))   # mix steep and shallow rays over the tasks
-    chunks = [(arrs, y0[order[k::cores * 4]]) for k in range(cores * 4)]
+    chunks = [y0[order[k::cores * 4]] for k in range(cores * 4)]
     ctx = mp.get_context("spawn")
-    with ctx.Pool(cores) as pool:
-        pool.map(_noop, range(cores))          # workers up, imports done, before the clock starts
+    with ctx.Pool(cores, initializer=_pool_init, initargs=(arrs,)) as pool:
+        pool.map(_noop, range(cores))          # workers up, tables and imports in place, before the clock starts
         t0 = time.time()
         res = pool.map(_scipy_chunk, chunks, chunksize=1)
         dt = time.time() - t0
     steps = sum(r[0] for r in res)
-    return {"value": steps / dt, "unit": "ray-steps/s", "cores": cores, "kind": "port",
+    return {"value": steps / dt, "unit": "ray-steps/s", "cores": cores, "kind": "port", "jit": False,
             "sample": f"{len(y0)} rays (every {stride}th of the 1e5-ray fan), 1000 km, {steps} ray-steps in {dt:.1f} s: "
                       f"oracle/scipy_port.py = scipy.integrate.solve_ivp(RK45, 4 terminal events, dense output) with a "
-                      f"NumPy right-hand side (pygenray's call pattern, un-jitted), spawn pool of {cores} processes"}
+                      f"NumPy right-hand side (pygenray's call pattern; un-jitted -- the reference jits its RHS with numba, "
+                      f"absent here -- so a real install is faster by the RHS share of a step), spawn pool of {cores} processes"}
 
 
 def _noop(_):
-    import oracle.scipy_port  # noqa: F401
     return 0
+
+
+def kernel_leg(arrs, n_rays, save, passes=4, amin=-20.0, amax=20.0, rays_lo=None):
+    """One more workload through the same device entry, a few passes: kernel time from HIP events on the launch
+    stream, accepted steps, the contract's algorithmic bytes and the fraction of the HBM peak they amount to."""
+    import torch
+    from pygenray_amd import _lib
+    from pygenray_amd.device_fan import DeviceFan, fan_y0
+    theta = np.linspace(amin, amax, n_rays)
+    if rays_lo is not None:
+        theta = theta[rays_lo[0]:rays_lo[1]]
+    env = _lib.EnvHandle(*arrs)
+    y0 = fan_y0(arrs, SOURCE_DEPTH, 0.0, -theta)
+    fan = DeviceFan(env, y0, 0.0, RANGE_M, S_SAVE, save=save, sample_major=True)
+    fan.run()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(passes):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fan.run(); e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ms = float(np.mean(ts))
+    steps = fan.ray_steps()
+    alive = max(fan.N - int((fan.status != 0).sum().item()), 1)
+    b_alg = 80.0 + (24.0 * S_SAVE / (steps / alive) if save else 0.0)
+    out = {"kernel_ms": ms, "frac": steps * b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ray_steps": steps,
+           "ray_steps_per_s": steps / (ms * 1e-3), "bytes_per_ray_step": b_alg, "passes": passes}
+    del fan
+    env.close()
+    return out
+
+
+def extra_legs():
+    """The kernels users hit beside the headline instance, timed by the same run: the
+    reference's DEFAULT environment handling (flat_earth_transform=True: smoothly non-uniform zin -> the
+    cubic-index depth look-up, kernel ZM = 5), configs[2] (range-dependent tables in HBM / L2), the per-GPU
+    fan size of configs[3] / configs[4] (1e6 rays, end state only) and the lone wave of the fan's 64 steepest
+    rays, whose latency is the 1e5-ray fan's floor."""
+    import pygenray_amd as pr
+    from pygenray_amd.environment import _unpack_envi
+    legs = {}
+    env_fe, _ = munk_tables(RANGE_M)
+    env_fe.flat_earth_transform(lat=35)
+    arrs_fe = _unpack_envi(env_fe, flatearth=True)
+    legs["flatearth_default"] = {
+        "workload": "configs[1] tables after OceanEnvironment2D's default flat-earth transform (non-uniform zin), 1e5 rays, 1000 km",
+        "kernel": "pgr_fan_kernel<true, 5, SAVE> (table + zin in LDS, cubic index estimate)",
+        "end_state": kernel_leg(arrs_fe, RAYS_PER_GPU, False), "trajectories": kernel_leg(arrs_fe, RAYS_PER_GPU, True)}
+    _, arrs_rd = munk_tables(RANGE_M, nr=101, sofar_slope=2e-4)
+    legs["range_dependent"] = {
+        "workload": "configs[2]: sofar axis + 2e-4 r over 101 columns, 1e5 rays, 1000 km",
+        "kernel": "pgr_fan_kernel<false, 4, SAVE> (tables in HBM / L2)",
+        "end_state": kernel_leg(arrs_rd, RAYS_PER_GPU, False), "trajectories": kernel_leg(arrs_rd, RAYS_PER_GPU, True)}
+    _, arrs1 = munk_tables(RANGE_M)
+    legs["rays_1e6"] = {
+        "workload": "configs[1] tables, 1e6 launch angles (the per-GPU fan of configs[3] / configs[4]), end state only",
+        "kernel": "pgr_fan_kernel<true, 4, 0>", "end_state": kernel_leg(arrs1, 1_000_000, False, passes=3)}
+    lone = {"end_state": kernel_leg(arrs1, RAYS_PER_GPU, False, rays_lo=(0, 64)),
+            "trajectories": kernel_leg(arrs1, RAYS_PER_GPU, True, rays_lo=(0, 64))}
+    return legs, lone
 
 
 def eigenray_leg(env_obj, n_rays):
@@ -266,6 +345,10 @@ def main(argv=None):
 
     _lib.load()
     env_obj, arrs = munk_tables(RANGE_M, nr=101, sofar_slope=2e-4) if args.range_dependent else munk_tables(RANGE_M)
+    if args.flat_earth:
+        from pygenray_amd.environment import _unpack_envi
+        env_obj.flat_earth_transform(lat=35)
+        arrs = _unpack_envi(env_obj, flatearth=True)
     env = _lib.EnvHandle(*arrs, device=local_rank)
     if args.waves_per_block:
         env.set_option("waves_per_block", args.waves_per_block)
@@ -340,30 +423,46 @@ def main(argv=None):
         mean_steps = local_steps / max(fan.N - int((fan.status != 0).sum().item()), 1)
         b_alg = 80.0 + (24.0 * S_SAVE / mean_steps if save else 0.0)
         achieved = local_steps * b_alg / (kern_ms * 1e-3) / 1e9
-        # HBM bytes and VALU wave-instructions per launch from the committed rocprofv3 PMC passes of this
-        # same command (profiles/r02_traffic.json: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE;
-        # SQ_INSTS_VALU), used only when they were taken at this ray count
+        # HBM bytes and VALU wave-instructions per launch from the committed rocprofv3 PMC passes of this same
+        # command (profiles/rNN_traffic.json: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE; SQ_INSTS_VALU).
+        # Counters describe a BINARY: the file records the sha256 of the gfx950 machine code they were taken with
+        # (pygenray_amd._lib.device_code_sha256) and they are reported only when the loaded library carries the
+        # same code and the run has the same shape -- otherwise `traffic` is null and says why.
         traffic = traffic_gb = valu = None
         tnote = "no committed PMC pass for this configuration"
-        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
-        if os.path.exists(tpath):
+        code_sha = _lib.device_code_sha256()
+        tfiles = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))
+        if tfiles:
+            tpath = os.path.join(ROOT, "profiles", tfiles[-1])
             try:
                 tj = json.load(open(tpath))
-                key = f"{args.layout}{'' if save else '-nosave'}"
-                if key in tj and tj[key].get("rays") == fan.N and not args.range_dependent:
+                key = (("rangedep-" if args.range_dependent else "") + ("flatearth-" if args.flat_earth else "")
+                       + f"{args.layout}{'' if save else '-nosave'}")
+                if key not in tj or tj[key].get("rays") != fan.N:
+                    tnote = f"profiles/{tfiles[-1]} holds no PMC pass of this workload"
+                elif tj.get("device_code_sha256") != code_sha:
+                    tnote = (f"profiles/{tfiles[-1]} was taken with other kernel code (device_code_sha256 "
+                             f"{str(tj.get('device_code_sha256'))[:12]}..., loaded {code_sha[:12]}...): counters withheld")
+                else:
                     traffic_gb = tj[key]["hbm_gb_per_launch"]
                     traffic = traffic_gb / (kern_ms * 1e-3)
                     valu = tj[key].get("valu_wave_instructions_per_launch")
-                    tnote = tj[key].get("note", "profiles/r02_traffic.json")
-            except Exception:
-                traffic = None
+                    tnote = tj[key].get("note", f"profiles/{tfiles[-1]}")
+            except Exception as exc:
+                traffic = traffic_gb = valu = None
+                tnote = f"profiles/{tfiles[-1]} unreadable ({type(exc).__name__})"
+        what = ("configs[2] range-dependent Munk fan" if args.range_dependent else "Munk fan") + (" on the flat-earth grid" if args.flat_earth else "")
+        metric = (BASELINE_METRIC if (fan.N == RAYS_PER_GPU and not args.range_dependent and not args.histogram and not args.flat_earth)
+                  else f"ray-steps/sec (whole node), {fan.N}-ray {what} to 1000 km"
+                       + (" + arrival-time histogram" if args.histogram else ""))
         out = {
-            "metric": "ray-steps/sec (whole node), 1e5-ray Munk fan to 1000 km; eigenray wall-clock",
+            "metric": metric,
             "value": value, "unit": "ray-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": (f"configs[2]: range-dependent Munk SSP (sofar axis + 2e-4 r, 101 columns) dz=1 m, "
                                     if args.range_dependent else "configs[1]: Munk SSP dz=1 m, ")
+                                   + ("flat-earth transformed tables (non-uniform zin), " if args.flat_earth else "")
                                    + f"{fan.N} launch angles per GPU "
                                    "linspace(-20,20), 1000 km, rtol 1e-9, fp64"
                                    + (", + 4096-bin arrival-time histogram (configs[4] shape)" if args.histogram else ""),
@@ -376,13 +475,14 @@ def main(argv=None):
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_gb_per_launch": traffic_gb, "traffic_source": tnote,
                          "algorithmic_gb_per_launch": local_steps * b_alg / 1e9,
-                         "kernel": f"pgr_fan_kernel<{'false' if args.range_dependent else 'true'}, 4, {1 if save else 0}> "
-                                   f"(table in {'HBM/L2' if args.range_dependent else 'LDS'}, zin = j * 1 m, "
+                         "kernel": f"pgr_fan_kernel<{'false' if args.range_dependent else 'true'}, {5 if args.flat_earth else 4}, {1 if save else 0}> "
+                                   f"(table in {'HBM/L2' if args.range_dependent else 'LDS'}, "
+                                   f"{'non-uniform zin, cubic index estimate' if args.flat_earth else 'zin = j * 1 m'}, "
                                    f"{'linspace save grid' if save else 'end state only'})", "kernel_ms": kern_ms,
                          "bytes_per_ray_step": b_alg,
                          "note": "algorithmic bytes per SURVEY 8(d); the stepper keeps state in "
                                  "VGPRs and the SSP table in LDS, so it is fp64-VALU bound, not HBM bound"},
-            "build": _lib.build_info(),
+            "build": _lib.build_info(), "device_code_sha256": code_sha,
         }
         if valu:
             slots = SIMDS * CLOCK_HZ / FP64_CYCLES_PER_WAVE_INSTR * kern_ms * 1e-3
@@ -398,6 +498,14 @@ def main(argv=None):
             out["cpu_baseline_c"] = cpu_baseline_c(arrs)
         if world == 1 and not args.no_eigenray:
             out["eigenray"] = eigenray_leg(env_obj, args.eigen_rays)
+        if world == 1 and not args.no_legs:
+            del fan   # (2.4 GB of trajectories back before the legs allocate theirs)
+            legs, lone = extra_legs()
+            out["legs"] = legs
+            # the fan cannot finish before its steepest rays do: the first wave of the fan (64 steepest rays) ALONE
+            out["lone_wave_ms"] = {"end_state": lone["end_state"]["kernel_ms"], "trajectories": lone["trajectories"]["kernel_ms"],
+                                   "note": "rays 0..63 of the 1e5-ray fan alone on the chip: the floor of the fan's kernel time"}
+            out["roofline"]["frac_rays_1e6_end_state"] = legs["rays_1e6"]["end_state"]["frac"]
         emit(out)
     if use_dist:
         dist.barrier()

@@ -387,6 +387,41 @@ def build_info():
     return L.pgr_build_info().decode()
 
 
+def device_code_sha256(path=None):
+    """sha256 of the gfx950 machine code (.text of the code object inside the library's fat binary): what the
+    kernels ARE, independent of symbol order and build paths (two builds of the same source give the same hash).
+    profiles/*_traffic.json records it next to the counters; bench.py reports counters only for the code they
+    were taken with."""
+    import hashlib
+    import struct
+
+    def sections(b):
+        shoff = struct.unpack_from("<Q", b, 0x28)[0]
+        shentsize, shnum, shstrndx = struct.unpack_from("<HHH", b, 0x3A)
+        secs = [struct.unpack_from("<IIQQQQIIQQ", b, shoff + i * shentsize) for i in range(shnum)]
+        stro = secs[shstrndx][4]
+        return {b[stro + s_[0]:b.index(b"\0", stro + s_[0])].decode(): (s_[4], s_[5]) for s_ in secs}
+
+    with open(path or LIB_PATH, "rb") as f:
+        b = f.read()
+    o, n = sections(b)[".hip_fatbin"]
+    fb = b[o:o + n]
+    if fb[:24] != b"__CLANG_OFFLOAD_BUNDLE__":
+        raise PgrError("unexpected fat binary layout")
+    cnt = struct.unpack_from("<Q", fb, 24)[0]
+    p = 32
+    for _ in range(cnt):
+        off, size, tl = struct.unpack_from("<QQQ", fb, p)
+        p += 24
+        triple = fb[p:p + tl].decode()
+        p += tl
+        if "gfx950" in triple:
+            elf = fb[off:off + size]
+            to, tn = sections(elf)[".text"]
+            return hashlib.sha256(elf[to:to + tn]).hexdigest()
+    raise PgrError("no gfx950 code object in the library")
+
+
 def arrival_histogram_device(device, t_ptr, t_stride, status_ptr, status_stride, n, t_min, t_max, nbins,
                              counts_ptr, stream=0):
     """pgr_arrival_histogram_device on raw device pointers (ints); see include/pgr.h."""

@@ -55,6 +55,32 @@ class DeviceFan:
         self.status = torch.empty(self.N, **i32)
         self.n_steps = torch.empty(self.N, **i32)
         self.n_rej = torch.empty(self.N, **i32)
+        # (the full-capacity buffers behind the views set_y0 hands out)
+        self.y0_buf, self.records_buf, self.end_buf = self.y0, self.records, (None if packed_end else self.end)
+        self.nb_buf, self.ns_buf, self.st_buf = self.n_bott, self.n_surf, self.status
+        self.nsteps_buf, self.nrej_buf = self.n_steps, self.n_rej
+        self.n_pad_min = int(n_pad or 0)
+
+    def set_y0(self, y0):
+        """New initial states for the same buffers (a fan of the same size or smaller: the per-ray outputs are
+        views of the first N entries): what a sharded fan or an eigenray search re-uses across calls instead of
+        nine fresh allocations per fan."""
+        y0 = np.ascontiguousarray(y0, dtype=np.float64).reshape(-1, 3)
+        n = len(y0)
+        cap = self.y0_buf.shape[0]
+        if n > cap or self.save:
+            raise ValueError("set_y0: the fan's buffers hold %d rays (end-state fans only)" % cap)
+        self.N = n
+        self.y0_buf[:n].copy_(torch.from_numpy(y0))
+        self.y0 = self.y0_buf[:n]
+        if self.packed_end:
+            self.records = self.records_buf[:max(self.n_pad_min, n)]
+            self.records[n:].zero_()
+            self.end = self.records[:n, 0:3]
+        else:
+            self.end = self.end_buf[:n]
+        self.n_bott, self.n_surf, self.status = self.nb_buf[:n], self.ns_buf[:n], self.st_buf[:n]
+        self.n_steps, self.n_rej = self.nsteps_buf[:n], self.nrej_buf[:n]
 
     def run(self):
         """Enqueue one pass of the hot path on torch's current stream (asynchronous)."""
@@ -69,6 +95,29 @@ class DeviceFan:
 
     def ray_steps(self):
         return int(self.n_steps.sum(dtype=torch.int64).item())
+
+
+def cached_end_state_fan(env_handle, y0, source_range, receiver_range, rtol=1e-9, atol=1e-6,
+                         terminate_backwards=True, max_steps=1_000_000, packed_end=False, n_pad=None):
+    """An end-state-only DeviceFan for these rays whose buffers live on the environment handle and grow only:
+    the many fans of a sharded search re-use one set of allocations."""
+    y0 = np.ascontiguousarray(y0, dtype=np.float64).reshape(-1, 3)
+    key = ("end_state_fan", bool(packed_end))
+    cache = env_handle.__dict__.setdefault("_fan_cache", {})
+    fan = cache.get(key)
+    need = max(len(y0), int(n_pad or 0))
+    if fan is None or fan.y0_buf.shape[0] < need or (packed_end and fan.records_buf.shape[0] < need):
+        cap = max(need, 64)
+        fan = DeviceFan(env_handle, np.zeros((cap, 3)), source_range, receiver_range, 1, rtol=rtol, atol=atol,
+                        terminate_backwards=terminate_backwards, save=False, max_steps=max_steps,
+                        packed_end=packed_end, n_pad=cap)
+        cache[key] = fan
+    fan.x0, fan.x1 = float(source_range), float(receiver_range)
+    fan.rtol, fan.atol, fan.max_steps = float(rtol), float(atol), int(max_steps)
+    fan.flags = (fan.flags & ~_lib.PGR_TERMINATE_BACKWARDS) | (_lib.PGR_TERMINATE_BACKWARDS if terminate_backwards else 0)
+    fan.n_pad_min = int(n_pad or 0)
+    fan.set_y0(y0)
+    return fan
 
 
 def fan_y0(arrays, source_depth, source_range, ode_angles_deg):

@@ -138,3 +138,183 @@ def arrival_time_histogram(t_end, status, bins, t_min, t_max, group=None, reduce
     if reduce and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
     return h
+
+
+# ------------------------------------------------------------------------------------------------------
+# The sharded path as API (REF = /root/reference/src/pygenray): what pygenray does with a process pool over
+# rays (REF/launch_rays.py:133-198) and over eigenray brackets (REF/eigenrays.py:122-157), one process per GPU.
+# ------------------------------------------------------------------------------------------------------
+def _rank_world(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def _fan_conventions(launch_angles):
+    """ODE launch angles and the angles a RayFan stores, as shoot_rays has them (Q1: REF/launch_rays.py:67,94,
+    180,251,318): fewer than 70 angles take the serial branch, whose double sign flip integrates +user."""
+    if type(launch_angles) is list:
+        launch_angles = np.array(launch_angles)
+    neg = -np.asarray(launch_angles, dtype=float)
+    if len(neg) < 70:
+        ode = -neg
+        return ode, ode
+    return neg, -neg
+
+
+def hip_end_state_compute(environment, flatearth, rtol=1e-9, terminate_backwards=True, device=None, atol=1e-6,
+                          max_steps=1_000_000):
+    """`compute(y0_local, x0, x1) -> packed end records [n, 5] on the device` through the HIP fan
+    (PGR_PACKED_END: the kernel writes the 40-byte records the all-gather ships); buffers are cached on the
+    environment's device handle and grow only."""
+    import torch as _torch
+    from .device_fan import cached_end_state_fan
+    from .launch_rays import _device_env
+
+    def compute(y0_local, x0, x1, backwards, n_pad):
+        dev = _torch.cuda.current_device() if device is None else int(device)
+        env, _ = _device_env(environment, flatearth, backwards, dev)
+        fan = cached_end_state_fan(env, y0_local, x0, x1, rtol=rtol, atol=atol, terminate_backwards=terminate_backwards,
+                                   max_steps=max_steps, packed_end=True, n_pad=n_pad)
+        fan.run()
+        return fan.records
+    return compute
+
+
+def shoot_rays_sharded(source_depth, source_range, launch_angles, receiver_range, environment, rtol=1e-9,
+                       terminate_backwards=True, debug=False, flatearth=True, group=None, device=None,
+                       compute=None, return_all=False):
+    """``shoot_rays`` over all ranks of `group`, end states only: launch angles are dealt to the ranks in a strided
+    fashion, every rank integrates its shard (HIP fan, the kernel writes the packed end records) and ONE all-gather
+    puts the whole fan's end states, in launch-angle order, on every rank -- the input of the eigenray bracketing
+    (REF/eigenrays.py:65-79) and of the arrival-time histogram.  Returns a ``RayFan`` with ONE column (the state at
+    ``receiver_range``; stored convention z -> -z, p -> -p; dropped rays have vanished, Q12), identical on every
+    rank and identical to the last column of the single-process ``shoot_rays`` fan.  Trajectories stay where they
+    are computed: shoot the rays you want to look at with ``shoot_rays`` / ``shoot_ray``.
+
+    ``compute(y0_local, x0, x1, backwards, n_pad) -> records [n_pad, 5]`` replaces the HIP fan in the gloo
+    rehearsals of the CPU test suite."""
+    from .launch_rays import _report_drops
+    from .environment import _unpack_envi, _check_monotone, _mirror_envi_arrays
+    from .host_physics import bilinear_interp
+    from .ray_objects import RayFan
+    rank, world = _rank_world(group)
+    ode, stored = _fan_conventions(launch_angles)
+    n = len(ode)
+    backwards = receiver_range < source_range
+    cin, cpin, rin, zin, depths, depth_ranges, bottom_angles = _unpack_envi(environment, flatearth=flatearth)
+    _check_monotone(rin, zin, depth_ranges)
+    if backwards:
+        cin, cpin, rin, depths, depth_ranges, bottom_angles = _mirror_envi_arrays(cin, cpin, rin, depths, depth_ranges, bottom_angles)
+    x0, x1 = (-source_range, -receiver_range) if backwards else (source_range, receiver_range)
+    if not (x0 < x1):
+        raise IndexError("list index out of range")    # as shoot_rays (REF/launch_rays.py:404)
+    c = bilinear_interp(x0, source_depth, rin, zin, cin)   # REF/launch_rays.py:140-144
+    idx = shard_indices(n, rank, world)
+    y0 = np.zeros((len(idx), 3))
+    y0[:, 1] = source_depth
+    y0[:, 2] = np.sin(np.radians(ode[idx])) / c
+    n_pad = (n + world - 1) // world
+    if compute is None:
+        compute = hip_end_state_compute(environment, flatearth, rtol=rtol, terminate_backwards=terminate_backwards,
+                                        device=device)
+    records = compute(y0, x0, x1, backwards, n_pad)
+    end, nb, ns, st = start_all_gather_records(records, n, group=group).finish()
+    end, nb, ns, st = (t.cpu().numpy() for t in (end, nb, ns, st))
+    if rank == 0:
+        _report_drops(st, debug)
+    keep = st == 0
+    M = int(keep.sum())
+    fan = RayFan.from_arrays(stored[keep], np.full((M, 1), float(receiver_range)), end[keep, 0:1].copy(),
+                             -end[keep, 1:2], -end[keep, 2:3], nb[keep].astype(np.int64), ns[keep].astype(np.int64),
+                             np.full(M, source_depth))
+    if return_all:
+        return fan, dict(end=end, n_bott=nb, n_surf=ns, status=st)
+    return fan
+
+
+def find_eigenrays_sharded(rays, receiver_depths, source_depth, source_range, receiver_range, num_range_save,
+                           environment, ztol=1, max_iter=20, group=None, refine=None, **kwargs):
+    """``find_eigenrays`` over all ranks of `group` (REF/eigenrays.py:11-203).  `rays` is the gathered fan
+    (``shoot_rays_sharded`` or any ``RayFan``), identical on every rank: every rank brackets on the WHOLE fan exactly
+    as the reference does (brackets across shard edges and across dropped rays included), the brackets of a receiver
+    depth are dealt to the ranks (bracket k -> rank k mod world; the reference maps them to a process pool,
+    REF/eigenrays.py:122-157), each rank runs the device-resident false-position loop on its own
+    (``pgr_eigen_refine``) and shoots its eigenrays with trajectories, and one all-gather of the (small) results
+    gives every rank the same ``EigenRays`` -- equal to the single-process result.
+
+    ``refine(z1s, z2s, th1s, th2s, receiver_depth) -> (found, th, r, T, Z, P, nb, ns)`` replaces the HIP refinement
+    in the CPU rehearsals."""
+    from .eigenrays import _find_eigenrays, _regula_falsi_batch
+    rank, world = _rank_world(group)
+    S = int(num_range_save)
+    if refine is None:
+        def refine(z1s, z2s, th1s, th2s, receiver_depth):
+            return _regula_falsi_batch(z1s, z2s, th1s, th2s, receiver_depth, source_depth, source_range, receiver_range,
+                                       num_range_save, environment, ztol, max_iter, kwargs)
+
+    def refine_dealt(z1s, z2s, th1s, th2s, receiver_depth):
+        nbk = len(z1s)
+        mine = np.arange(rank, nbk, world)
+        if len(mine):
+            found, th, r, T, Z, P, nb, ns = refine(z1s[mine], z2s[mine], th1s[mine], th2s[mine], receiver_depth)
+            part = (mine, np.asarray(found), np.asarray(th), np.asarray(r), T[found], Z[found], P[found],
+                    np.asarray(nb)[found], np.asarray(ns)[found])
+        else:
+            part = (mine, np.zeros(0, bool), np.zeros(0), None, np.zeros((0, S)), np.zeros((0, S)), np.zeros((0, S)),
+                    np.zeros(0, np.int64), np.zeros(0, np.int64))
+        parts = [part]
+        if world > 1:
+            parts = [None] * world
+            dist.all_gather_object(parts, part, group=group)
+        found = np.zeros(nbk, bool); th = np.zeros(nbk)
+        T = np.zeros((nbk, S)); Z = np.zeros((nbk, S)); P = np.zeros((nbk, S))
+        nb = np.zeros(nbk, np.int64); ns = np.zeros(nbk, np.int64)
+        r = np.linspace(source_range, receiver_range, S)
+        for (m, f, t_, r_, T_, Z_, P_, nb_, ns_) in parts:
+            found[m] = f
+            th[m] = t_
+            hit = m[f]
+            T[hit], Z[hit], P[hit], nb[hit], ns[hit] = T_, Z_, P_, nb_, ns_
+            if r_ is not None and len(hit):
+                r = r_
+        return found, th, r, T, Z, P, nb, ns
+
+    return _find_eigenrays(rays, receiver_depths, source_depth, S, environment, refine_dealt)
+
+
+def arrival_histogram_sharded(source_depth, source_range, launch_angles, receiver_range, environment, bins, t_min,
+                              t_max, rtol=1e-9, terminate_backwards=True, flatearth=True, group=None, device=None,
+                              compute=None):
+    """Arrival-time histogram of a fan sharded over the ranks (BASELINE configs[4]): every rank integrates its strided
+    shard and bins ITS rays on the device (``pgr_arrival_histogram_device``, straight from the packed end records),
+    ONE all-reduce (sum) of the int64 counts puts the whole fan's histogram on every rank -- no ray data travels.
+    Returns ``(counts [bins] int64 ndarray, edges [bins + 1])`` with ``np.histogram``'s bin rule."""
+    from .environment import _unpack_envi, _check_monotone, _mirror_envi_arrays
+    from .host_physics import bilinear_interp
+    rank, world = _rank_world(group)
+    ode, _ = _fan_conventions(launch_angles)
+    n = len(ode)
+    backwards = receiver_range < source_range
+    cin, cpin, rin, zin, depths, depth_ranges, bottom_angles = _unpack_envi(environment, flatearth=flatearth)
+    _check_monotone(rin, zin, depth_ranges)
+    if backwards:
+        cin, cpin, rin, depths, depth_ranges, bottom_angles = _mirror_envi_arrays(cin, cpin, rin, depths, depth_ranges, bottom_angles)
+    x0, x1 = (-source_range, -receiver_range) if backwards else (source_range, receiver_range)
+    c = bilinear_interp(x0, source_depth, rin, zin, cin)
+    idx = shard_indices(n, rank, world)
+    y0 = np.zeros((len(idx), 3))
+    y0[:, 1] = source_depth
+    y0[:, 2] = np.sin(np.radians(ode[idx])) / c
+    if compute is None:
+        compute = hip_end_state_compute(environment, flatearth, rtol=rtol, terminate_backwards=terminate_backwards,
+                                        device=device)
+    records = compute(y0, x0, x1, backwards, len(idx))
+    ints = records[:, 3:5].view(torch.int32) if records.is_cuda else records[:, 3:5].contiguous().view(torch.int32)
+    h = arrival_time_histogram(records[:len(idx), 0], ints[:len(idx), 2], bins, t_min, t_max, group=group, reduce=True)
+    return h.cpu().numpy(), np.linspace(float(t_min), float(t_max), int(bins) + 1)
+
+
+__all__ = ["shard_indices", "shoot_rays_sharded", "find_eigenrays_sharded", "arrival_histogram_sharded",
+           "shoot_fan_sharded", "all_gather_fan", "start_all_gather_fan", "start_all_gather_records",
+           "arrival_time_histogram", "hip_compute", "hip_end_state_compute"]

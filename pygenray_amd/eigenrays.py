@@ -62,20 +62,23 @@ def _regula_falsi_batch(z1, z2, th1, th2, receiver_depth, source_depth, source_r
     return found, th_found, r, T, Z, P, nb, ns
 
 
-def find_eigenrays(rays, receiver_depths, source_depth, source_range, receiver_range,
-                   num_range_save, environment, ztol=1, max_iter=20, num_workers=None, **kwargs):
-    """Find eigenrays from an initial ray fan by regula falsi (REF/eigenrays.py:11-203).
+def _bracket(rays, receiver_depth):
+    """Brackets of one receiver depth on the WHOLE fan, exactly as REF/eigenrays.py:65-79: sign changes of
+    z_end + receiver_depth between neighbouring fan rays (dropped rays have vanished from the fan, Q12, so a
+    bracket may span one)."""
+    depth_sign = np.sign(rays.zs[:, -1] + receiver_depth)
+    starts = np.where(np.diff(depth_sign))[0]
+    return starts, rays.zs[starts, -1], rays.zs[starts + 1, -1], rays.thetas[starts], rays.thetas[starts + 1]
 
-    ``num_workers`` is accepted and ignored.  ``kwargs`` are those of ``shoot_ray``
-    (``rtol, terminate_backwards, debug, flatearth``).  Returns ``EigenRays``."""
+
+def _find_eigenrays(rays, receiver_depths, source_depth, num_range_save, environment, refine):
+    """The frame of find_eigenrays (REF/eigenrays.py:62-203) around `refine(z1s, z2s, th1s, th2s, receiver_depth)
+    -> (found, th, r, T, Z, P, nb, ns)` over ALL brackets of one receiver depth: the single-GPU search refines them in
+    one batch, the sharded one (distributed.find_eigenrays_sharded) deals them to the ranks and gathers."""
     erays_dict, num_eigenrays, num_found, failed = {}, {}, {}, {}
     for rd_idx, receiver_depth in enumerate(receiver_depths):
-        # REF/eigenrays.py:65-79
-        depth_sign = np.sign(rays.zs[:, -1] + receiver_depth)
-        starts = np.where(np.diff(depth_sign))[0]
+        starts, z1s, z2s, th1s, th2s = _bracket(rays, receiver_depth)
         num_eigenrays[receiver_depth] = len(starts)
-        z1s, z2s = rays.zs[starts, -1], rays.zs[starts + 1, -1]
-        th1s, th2s = rays.thetas[starts], rays.thetas[starts + 1]
         failed[rd_idx] = []
         if len(starts) == 0:
             erays_dict[rd_idx] = RayFan.from_arrays(
@@ -84,9 +87,7 @@ def find_eigenrays(rays, receiver_depths, source_depth, source_range, receiver_r
                 np.zeros(0, np.int64), np.zeros(0))
             num_found[rd_idx] = 0
             continue
-        found, th, r, T, Z, P, nb, ns = _regula_falsi_batch(
-            z1s, z2s, th1s, th2s, receiver_depth, source_depth, source_range, receiver_range,
-            num_range_save, environment, ztol, max_iter, kwargs)
+        found, th, r, T, Z, P, nb, ns = refine(z1s, z2s, th1s, th2s, receiver_depth)
         for k in np.where(~found)[0]:
             failed[rd_idx].append((th1s[k], th2s[k]))
         M = int(found.sum())
@@ -95,6 +96,18 @@ def find_eigenrays(rays, receiver_depths, source_depth, source_range, receiver_r
             np.full(M, source_depth))
         num_found[rd_idx] = M
     return EigenRays(receiver_depths, erays_dict, environment, num_eigenrays, num_found, failed)
+
+
+def find_eigenrays(rays, receiver_depths, source_depth, source_range, receiver_range,
+                   num_range_save, environment, ztol=1, max_iter=20, num_workers=None, **kwargs):
+    """Find eigenrays from an initial ray fan by regula falsi (REF/eigenrays.py:11-203).
+
+    ``num_workers`` is accepted and ignored.  ``kwargs`` are those of ``shoot_ray``
+    (``rtol, terminate_backwards, debug, flatearth``).  Returns ``EigenRays``."""
+    def refine(z1s, z2s, th1s, th2s, receiver_depth):
+        return _regula_falsi_batch(z1s, z2s, th1s, th2s, receiver_depth, source_depth, source_range, receiver_range,
+                                   num_range_save, environment, ztol, max_iter, kwargs)
+    return _find_eigenrays(rays, receiver_depths, source_depth, num_range_save, environment, refine)
 
 
 __all__ = ["find_eigenrays"]
