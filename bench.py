@@ -417,6 +417,30 @@ def main(argv=None):
     else:
         total_steps = local_steps
 
+    # configs[3] over the ranks (every rank takes part): the fan's launch angles are dealt to the ranks, ONE all-gather
+    # of the end records puts the fan on every rank, every rank brackets on the whole fan, the brackets are dealt to the
+    # ranks for the device-resident false-position loop, one small gather collects the eigenrays
+    eig_sharded = None
+    if use_dist and not args.no_eigenray:
+        from pygenray_amd.distributed import shoot_rays_sharded, find_eigenrays_sharded
+        angles = np.linspace(-20, 20, args.eigen_rays)
+        for _ in range(2):   # second run: tables resident, buffers allocated
+            fence()
+            t_a = time.perf_counter()
+            gfan = shoot_rays_sharded(SOURCE_DEPTH, 0.0, angles, RANGE_M, env_obj, flatearth=False, device=local_rank)
+            t_b = time.perf_counter()
+            ger = find_eigenrays_sharded(gfan, [1000.0], SOURCE_DEPTH, 0.0, RANGE_M, 2, env_obj, ztol=1, max_iter=20,
+                                         debug=False, flatearth=False, quiet=True, device=local_rank)
+            fence()
+            t_c = time.perf_counter()
+        tt = torch.tensor([t_c - t_a, t_b - t_a], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        eig_sharded = {"wall_s": float(tt[0].item()), "fan_s": float(tt[1].item()), "fan_rays": int(args.eigen_rays),
+                       "ranks": world, "brackets": int(ger.num_eigenrays[1000.0]), "found": int(ger.num_eigenrays_found[0]),
+                       "failed": len(ger.failed_eray_theta_brackets[0]),
+                       "config": "configs[3] sharded: pygenray_amd.distributed.shoot_rays_sharded (strided shards, all-gather "
+                                 "of 40-byte end records) + find_eigenrays_sharded (brackets dealt to the ranks)"}
+
     if rank == 0:
         value = total_steps * args.steps / dt
         # B_alg = 80 B (state in + out) + 24 B per saved (T,z,p) sample
@@ -498,6 +522,8 @@ def main(argv=None):
             out["cpu_baseline_c"] = cpu_baseline_c(arrs)
         if world == 1 and not args.no_eigenray:
             out["eigenray"] = eigenray_leg(env_obj, args.eigen_rays)
+        if eig_sharded is not None:
+            out["eigenray_sharded"] = eig_sharded
         if world == 1 and not args.no_legs:
             del fan   # (2.4 GB of trajectories back before the legs allocate theirs)
             legs, lone = extra_legs()

@@ -131,6 +131,34 @@ int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, double sourc
                          double* p, double* end_state, int32_t* n_bott, int32_t* n_surf,
                          int32_t* status, int32_t* n_steps, int32_t* n_rej, void* stream);
 
+/* Initial states on the device (REF/launch_rays.py:140-144, 284-285): y0[k] = [0, source_depth,
+ * sin(radians(ode_angles_deg[k])) / c_source], the sine correctly rounded (the arithmetic pgr_eigen_refine uses for its
+ * trial rays); DEVICE pointers, enqueued on `stream`, returns without synchronising.  c_source = c at the source (the
+ * caller's bilinear_interp, REF/launch_rays.py:140). */
+int pgr_initial_states_device(int device, const double* ode_angles_deg, int64_t N, double source_depth,
+                              double c_source, double* y0, void* stream);
+
+/* A fan whose results stay in HBM.  pgr_fan_launch uploads y0[N][3] (HOST) -- or, when y0 is NULL, the N ODE launch
+ * angles ode_angles_deg (HOST, degrees), from which the initial states are computed on the device as above --
+ * enqueues the fan on the environment's stream and returns as soon as the upload is done: the kernel is still running.
+ * S = num_range_save of the trajectories kept on the device ([S][N], the save grid is np.linspace(source_range,
+ * receiver_range, S)); S = 0: end states only.  flags as pgr_shoot_fan (PGR_TERMINATE_BACKWARDS, PGR_EXACT_*,
+ * PGR_STORED_SIGN).  pgr_fan_wait blocks until the kernel has finished and tells the ray count and how many have
+ * status 0.  pgr_fan_fetch_rays copies the per-ray arrays ([N], any may be NULL) to HOST buffers; pgr_fan_fetch_samples
+ * copies the trajectories asked for (T, z, p: HOST [S][N], any may be NULL; with PGR_COMPACT [S][M], dropped rays
+ * squeezed out as in a pygenray RayFan, REF/launch_rays.py:166-171) -- page faults of fresh destination buffers
+ * pipelined with the copies.  Both wait for the kernel themselves.  What pygenray's RayFan holds as host arrays
+ * (REF/launch_rays.py:166-186) crosses PCIe only when somebody asks for it. */
+typedef struct pgr_fan pgr_fan;
+int pgr_fan_launch(pgr_env* env, const double* y0, const double* ode_angles_deg, double source_depth, double c_source,
+                   int64_t N, double source_range, double receiver_range, int32_t S, double rtol, double atol,
+                   uint32_t flags, int64_t max_steps, pgr_fan** fan);
+int pgr_fan_wait(pgr_fan* fan, int64_t* n_rays, int64_t* n_ok);
+int pgr_fan_fetch_rays(pgr_fan* fan, double* end_state, int32_t* n_bott, int32_t* n_surf, int32_t* status,
+                       int32_t* n_steps, int32_t* n_rej);
+int pgr_fan_fetch_samples(pgr_fan* fan, double* T, double* z, double* p, uint32_t flags);
+void pgr_fan_destroy(pgr_fan* fan);
+
 /* Eigenray refinement: pygenray's _find_single_eigenray (REF/eigenrays.py:206-268) for nbk brackets at
  * once, the whole false-position loop on the device.  Per bracket k the fan rays th1[k], th2[k] (user
  * launch angles, degrees) ended at stored-convention depths z1[k], z2[k] on either side of
@@ -142,8 +170,10 @@ int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, double sourc
  * replaces the bracket end on its side; give up after max_iter + 2 trial rays (REF/eigenrays.py:265-268).
  * Everything is enqueued on the environment's stream; the host only reads back the count of active
  * brackets after each iteration.  HOST arrays in and out:
- *   theta[k]  the eigenray's launch angle (user convention) or NaN;   state[k]  1 found, 2 trial ray
- *   dropped (the reference prints "Failed to find eigen ray" and gives up), 3 iteration limit;
+ *   theta[k]  state 1: the eigenray's launch angle (user convention); state 2: the angle of the trial ray that was
+ *   dropped (what the reference prints in its failure message); state 3: the next trial angle the loop would have
+ *   shot;   state[k]  1 found, 2 trial ray dropped (the reference prints "Failed to find eigen ray" and gives
+ *   up), 3 iteration limit;
  *   n_trial[k] trial rays shot;  z_end[k], t_end[k] stored-convention end depth / arrival time of the
  *   last trial ray.  *launches = fan launches made.  c_source = c at the source (the caller's
  *   bilinear_interp, REF/launch_rays.py:284). */

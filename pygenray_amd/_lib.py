@@ -366,6 +366,89 @@ class EnvHandle:
         return out
 
 
+class FanHandle:
+    """A fan whose results stay in HBM (pgr_fan_*, include/pgr.h): launched in the constructor (returns while the
+    kernel runs), per-ray arrays and trajectories fetched on demand."""
+
+    def __init__(self, env, x0, x1, S, y0=None, ode_angles_deg=None, source_depth=0.0, c_source=1.0, rtol=1e-9,
+                 atol=1e-6, terminate_backwards=True, max_steps=1_000_000, stored_sign=False, exact_samples=False,
+                 exact_bisection=False):
+        L = load()
+        L.pgr_fan_launch.restype = ctypes.c_int
+        L.pgr_fan_launch.argtypes = [_vp, _vp, _vp, ctypes.c_double, ctypes.c_double, _i64, ctypes.c_double, ctypes.c_double,
+                                     ctypes.c_int32, ctypes.c_double, ctypes.c_double, ctypes.c_uint32, _i64, ctypes.POINTER(_vp)]
+        L.pgr_fan_wait.restype = ctypes.c_int
+        L.pgr_fan_wait.argtypes = [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]
+        L.pgr_fan_fetch_rays.restype = ctypes.c_int
+        L.pgr_fan_fetch_rays.argtypes = [_vp] * 7
+        L.pgr_fan_fetch_samples.restype = ctypes.c_int
+        L.pgr_fan_fetch_samples.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_uint32]
+        L.pgr_fan_destroy.restype = None
+        L.pgr_fan_destroy.argtypes = [_vp]
+        self._env = env   # keeps the environment (its stream, its tables) alive
+        if y0 is not None:
+            y0 = _c(y0).reshape(-1, 3)
+            n = len(y0)
+        else:
+            ode_angles_deg = _c(ode_angles_deg).reshape(-1)
+            n = len(ode_angles_deg)
+        self.N, self.S = n, int(S)
+        flags = (PGR_TERMINATE_BACKWARDS if terminate_backwards else 0) | (PGR_STORED_SIGN if stored_sign else 0) | \
+            (PGR_EXACT_SAMPLES if exact_samples else 0) | (PGR_EXACT_BISECTION if exact_bisection else 0)
+        h = _vp()
+        check(L.pgr_fan_launch(env._h, _vptr(y0), _vptr(ode_angles_deg), float(source_depth), float(c_source), n,
+                               float(x0), float(x1), self.S, float(rtol), float(atol), flags, int(max_steps),
+                               ctypes.byref(h)))
+        self._h = h
+        self.M = None
+
+    def wait(self):
+        n, m = _i64(0), _i64(0)
+        check(load().pgr_fan_wait(self._h, ctypes.byref(n), ctypes.byref(m)))
+        self.M = int(m.value)
+        return int(n.value), self.M
+
+    def fetch_rays(self):
+        n = self.N
+        end = np.empty((n, 3))
+        nb = np.empty(n, np.int32); ns = np.empty(n, np.int32); st = np.empty(n, np.int32)
+        n1 = np.empty(n, np.int32); n2 = np.empty(n, np.int32)
+        check(load().pgr_fan_fetch_rays(self._h, _vptr(end), _vptr(nb), _vptr(ns), _vptr(st), _vptr(n1), _vptr(n2)))
+        self.M = int(np.count_nonzero(st == 0))
+        return dict(end=end, n_bott=nb, n_surf=ns, status=st, n_steps=n1, n_rej=n2)
+
+    def fetch_samples(self, which=("T", "z", "p"), compact=True):
+        """-> dict name -> (S, M) array (M = surviving rays when `compact`, else all N; dropped rays are NaN then)."""
+        if self.M is None:
+            self.wait()
+        cols = self.M if compact else self.N
+        bufs = {k: (np.empty((self.S, self.N)) if k in which else None) for k in ("T", "z", "p")}
+        check(load().pgr_fan_fetch_samples(self._h, _vptr(bufs["T"]), _vptr(bufs["z"]), _vptr(bufs["p"]),
+                                           PGR_COMPACT if compact else 0))
+        return {k: (v.reshape(-1)[:self.S * cols].reshape(self.S, cols) if cols != self.N else v)
+                for k, v in bufs.items() if v is not None}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().pgr_fan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def initial_states_device(device, ang_ptr, n, source_depth, c_source, y0_ptr, stream=0):
+    """pgr_initial_states_device on raw device pointers (ints)."""
+    L = load()
+    L.pgr_initial_states_device.restype = ctypes.c_int
+    L.pgr_initial_states_device.argtypes = [ctypes.c_int, _vp, _i64, ctypes.c_double, ctypes.c_double, _vp, _vp]
+    check(L.pgr_initial_states_device(int(device), _vp(ang_ptr), int(n), float(source_depth), float(c_source), _vp(y0_ptr),
+                                      _vp(stream or None)))
+
+
 def debug_math(a, b):
     a = _c(a); b = _c(b)
     out = np.empty((len(a), 9))

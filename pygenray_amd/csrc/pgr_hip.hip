@@ -27,11 +27,14 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
+#include <time.h>
 #include <float.h>
 #include <string>
 #include <vector>
 #include <mutex>
 #include <thread>
+#include <atomic>
 #include <initializer_list>
 
 #include "../../include/pgr.h"
@@ -207,6 +210,16 @@ __global__ void pgr_math_kernel(const double* a, const double* b, int64_t M, dou
 // ====================================================================================
 static thread_local std::string g_err;
 
+// PGR_TRACE=1 in the environment: wall-clock marks of the host-pointer paths on stderr (diagnostics)
+static bool trace_on() { static const bool on = getenv("PGR_TRACE") != nullptr; return on; }
+static double trace_now()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+#define PGR_MARK(t0, what) do { if (trace_on()) fprintf(stderr, "[pgr] %8.2f ms  %s\n", trace_now() - (t0), what); } while (0)
+
 static int fail(const std::string& m)
 {
     g_err = m;
@@ -236,12 +249,24 @@ struct pgr_env {
     // small fans of an eigenray search do not pay 11 hipMalloc/hipFree per call)
     void* ws = nullptr;
     size_t ws_bytes = 0;
+    // device buffers of destroyed pgr_fan handles, kept for the next one (hipMalloc + hipFree of 2.4 GB per fan cost
+    // more than the kernel's launch; hipFree also waits for the whole device): at most 4 buffers / 64 GB
+    std::vector<std::pair<void*, size_t>> fan_pool;
+    std::mutex fan_pool_mutex;
+    void* ws2 = nullptr;   // second grow-only workspace: the compacted trajectories of PGR_COMPACT
+    size_t ws2_bytes = 0;
     std::mutex ws_mutex;
-    // ring of small buffers for the per-launch wave placement (cost[2048] + map[2048])
-    static constexpr int kPlaceRing = 8;
-    void* place_buf = nullptr;     // owned through `allocs`
-    size_t place_slot_bytes = 0;
-    int place_next = 0;
+    // small buffers for the per-launch wave placement (cost[waves] + map[slots]): a slot is handed to a launch and
+    // an event is recorded on that launch's stream behind its fan kernel; the slot is taken again only when the
+    // event has completed -- however many launches are in flight on however many user streams, none reads a map
+    // another launch is writing (the pool grows instead)
+    struct PlaceSlot {
+        void* buf = nullptr;
+        size_t bytes = 0;
+        hipEvent_t ev = nullptr;
+        bool in_flight = false;
+    };
+    std::vector<PlaceSlot> place_slots;
     std::mutex place_mutex;
     int range_indep = 0;
     int lds_path = 0;
@@ -498,7 +523,13 @@ extern "C" void pgr_env_destroy(pgr_env* env)
     if (!env) return;
     (void)hipSetDevice(env->device);
     for (void* p : env->allocs) (void)hipFree(p);
+    for (auto& ps : env->place_slots) {
+        if (ps.ev) { (void)hipEventSynchronize(ps.ev); (void)hipEventDestroy(ps.ev); }
+        if (ps.buf) (void)hipFree(ps.buf);
+    }
     if (env->ws) (void)hipFree(env->ws);
+    if (env->ws2) (void)hipFree(env->ws2);
+    for (auto& pb : env->fan_pool) (void)hipFree(pb.first);
     if (env->stream) (void)hipStreamDestroy(env->stream);
     delete env;
 }
@@ -677,9 +708,10 @@ extern "C" int pgr_env_query(const pgr_env* env, int what)
 // Builds the slot -> wave map for this launch on `st` (see pgr_wave_place); returns the map and
 // the grid size through the references, or leaves map null when scheduling is off / not useful.
 static int schedule_waves(pgr_env* env, const double* y0, int64_t N, int64_t waves, int W, hipStream_t st,
-                          const int*& map_out, int64_t& blocks)
+                          const int*& map_out, int64_t& blocks, int& slot_out)
 {
     map_out = nullptr;
+    slot_out = -1;
     if (env->place == 0 || env->waves_per_block != 0 || W < 5 || waves > (1 << 27)) return 0;
     const int64_t cus = env->num_cus;
     int mode, B;
@@ -695,16 +727,29 @@ static int schedule_waves(pgr_env* env, const double* y0, int64_t N, int64_t wav
     std::lock_guard<std::mutex> lock(env->place_mutex);  // host threads may share an env
     size_t n_slots = (size_t)B * W;
     size_t need = ((size_t)waves * 4 + n_slots * 4 + 511) & ~(size_t)255;
-    if (need > env->place_slot_bytes) {  // grow-only ring (previous launches may still read theirs:
-        // the old buffer is kept until the env dies)
-        size_t sz = need > 65536 ? need : 65536;
-        void* nb = nullptr;
-        HIPCHK(hipMalloc(&nb, sz * pgr_env::kPlaceRing));
-        env->allocs.push_back(nb);
-        env->place_buf = nb;
-        env->place_slot_bytes = sz;
+    int pick = -1;
+    for (size_t k = 0; k < env->place_slots.size() && pick < 0; k++) {
+        pgr_env::PlaceSlot& ps = env->place_slots[k];
+        if (ps.in_flight && hipEventQuery(ps.ev) == hipSuccess) ps.in_flight = false;
+        if (!ps.in_flight) pick = (int)k;
     }
-    char* slot = (char*)env->place_buf + (size_t)(env->place_next++ % pgr_env::kPlaceRing) * env->place_slot_bytes;
+    if (pick < 0) {
+        if (env->place_slots.size() >= 4096) return fail("pgr_shoot_fan: more than 4096 fans in flight on one environment");
+        env->place_slots.emplace_back();
+        pick = (int)env->place_slots.size() - 1;
+        HIPCHK(hipEventCreateWithFlags(&env->place_slots[pick].ev, hipEventDisableTiming));
+    }
+    pgr_env::PlaceSlot& ps = env->place_slots[pick];
+    if (need > ps.bytes) {
+        if (ps.buf) (void)hipFree(ps.buf);    // (not in flight: nobody reads it)
+        ps.buf = nullptr; ps.bytes = 0;
+        const size_t sz = need > 65536 ? need : 65536;
+        HIPCHK(hipMalloc(&ps.buf, sz));
+        ps.bytes = sz;
+    }
+    ps.in_flight = true;   // (the event is recorded by the caller behind the fan kernel: place_release)
+    slot_out = pick;
+    char* slot = (char*)ps.buf;
     float* cost = (float*)slot;
     int* map = (int*)(slot + (((size_t)waves * 4 + 255) & ~(size_t)255));
     HIPCHK(hipMemsetAsync(map, 0xFF, n_slots * sizeof(int), st));
@@ -783,6 +828,7 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
     int64_t blocks;
     size_t lds;
     bool want_ring = false;
+    int place_slot = -1;
     if (lds_tab) {
         // one workgroup per CU (the LDS table is per workgroup): the smallest workgroup that
         // covers the fan in a single round, capped at 8 waves
@@ -795,7 +841,7 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
         threads = wpb * 64;
         blocks = (N + threads - 1) / threads;
         // cost-aware scheduling of the waves (placement, priorities, homogeneous workgroups)
-        if (schedule_waves(env, y0, N, waves, wpb, st, a.wave_map, blocks)) return -1;
+        if (schedule_waves(env, y0, N, waves, wpb, st, a.wave_map, blocks, place_slot)) return -1;
         lds = tab_bytes + zx_bytes;
     } else {
         // kernels that save trajectories give the workgroup's last wave slot to the writer of the LDS sample ring
@@ -810,7 +856,7 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
             int W = waves <= cap * (int64_t)env->num_cus ? (int)((waves + env->num_cus - 1) / env->num_cus) : cap;
             const int* m = nullptr;
             int64_t nb2 = blocks;
-            if (schedule_waves(env, y0, N, waves, W, st, m, nb2)) return -1;
+            if (schedule_waves(env, y0, N, waves, W, st, m, nb2, place_slot)) return -1;
             if (m) { a.wave_map = m; blocks = nb2; wpb = W; }
         }
         threads = wpb * 64;
@@ -862,7 +908,14 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
     }
 #undef PGR_LAUNCH
 #undef PGR_LAUNCH1
-    HIPCHK(hipGetLastError());
+    const hipError_t launch_err = hipGetLastError();
+    if (place_slot >= 0) {
+        // the placement map is this launch's until its fan kernel has run
+        std::lock_guard<std::mutex> lock(env->place_mutex);
+        pgr_env::PlaceSlot& ps = env->place_slots[place_slot];
+        if (launch_err != hipSuccess || hipEventRecord(ps.ev, st) != hipSuccess) ps.in_flight = false;
+    }
+    if (launch_err != hipSuccess) return fail(std::string("fan kernel launch: ") + hipGetErrorString(launch_err));
     return 0;
 }
 
@@ -885,34 +938,186 @@ __global__ void pgr_gather_cols(const double* __restrict__ src, double* __restri
     dst[s * M + m] = src[s * N + idx[m]];
 }
 
-// Fault in every page of the caller's output buffers from up to 16 threads: each page's first byte is
-// read and written back UNCHANGED (a write access, so the page is really allocated, but nothing the
-// caller may still want -- a reused buffer whose tail the copies below do not overwrite -- is altered).
-static void prefault_outputs(std::initializer_list<double*> bufs, size_t bytes)
-{
-    const size_t page = 4096;
-    unsigned nt = std::thread::hardware_concurrency();
-    nt = nt < 1 ? 1 : (nt > 16 ? 16 : nt);
+// Device -> host copy of a list of (large) arrays into the caller's pageable buffers, pipelined with the page
+// faults those buffers still owe.  Measured on the one-GPU box (scripts/probes/pcie_probe2.py, 0.8 GB pieces): a D2H
+// copy into never-touched NumPy memory runs at the page-fault rate of one thread (15-17 GB/s), into touched memory
+// at 56 GB/s; touching 0.8 GB from 16 threads takes 6 ms.  So: helper threads fault the destination pages in, IN
+// ORDER (every page's first byte is read and written back unchanged -- a write access, so the page is really
+// allocated, but a reused buffer keeps what the copies do not overwrite), and publish how far they are; the calling
+// thread waits for `ready` (the kernel, typically running meanwhile), then copies piece by piece as soon as a
+// piece's pages are there.  The copies of the first array overlap the faults of the following ones.
+namespace {
+struct D2HJob { void* dst; const void* src; size_t bytes; };
+
+struct OrderedPrefault {
+    std::vector<D2HJob> jobs;
+    std::vector<size_t> start;          // byte offset of each job in the concatenation
+    size_t total = 0;
+    static constexpr size_t kPiece = (size_t)16 << 20;
     std::vector<std::thread> th;
-    for (double* b : bufs) {
-        char* base = (char*)b;
-        size_t npages = (bytes + page - 1) / page;
-        size_t per = (npages + nt - 1) / nt;
-        for (unsigned k = 0; k < nt; k++) {
-            size_t p0 = (size_t)k * per, p1 = p0 + per < npages ? p0 + per : npages;
-            if (p0 >= p1) break;
-            th.emplace_back([base, bytes, p0, p1, page]() {
-                for (size_t q = p0; q < p1; q++) {
-                    size_t o = q * page;
-                    if (o < bytes) {
-                        volatile char* c = (volatile char*)base + o;
-                        *c = *c;
+    std::atomic<size_t> next_piece{0};
+    std::vector<std::atomic<unsigned char>> done;   // per piece
+    std::vector<std::atomic<int>> reg;              // per job: 0 pages not all there, 1 being registered, 2 registered, 3 registration failed
+    size_t n_pieces = 0;
+    int device = 0;
+
+    OrderedPrefault(const std::vector<D2HJob>& j, int dev) : jobs(j), device(dev)
+    {
+        for (auto& q : jobs) { start.push_back(total); total += q.bytes; }
+        n_pieces = (total + kPiece - 1) / kPiece;
+        done = std::vector<std::atomic<unsigned char>>(n_pieces);
+        for (auto& d : done) d.store(0);
+        reg = std::vector<std::atomic<int>>(jobs.size());
+        for (auto& r : reg) r.store(0);
+    }
+    // touch the pages of the concatenation's bytes [a, b)
+    void touch(size_t a, size_t b)
+    {
+        for (size_t k = 0; k < jobs.size(); k++) {
+            const size_t lo = a > start[k] ? a : start[k], hi = b < start[k] + jobs[k].bytes ? b : start[k] + jobs[k].bytes;
+            if (lo >= hi) continue;
+            char* base = (char*)jobs[k].dst;
+            size_t o = lo - start[k];
+            const size_t e = hi - start[k];
+            const size_t first_page = ((uintptr_t)(base + o) + 4095) & ~(uintptr_t)4095;
+            { volatile char* c = (volatile char*)base + o; *c = *c; }
+            for (uintptr_t q = first_page; q < (uintptr_t)(base + e); q += 4096) { volatile char* c = (volatile char*)q; *c = *c; }
+        }
+    }
+    bool job_pages_there(size_t k) const
+    {
+        if (jobs[k].bytes == 0) return true;
+        for (size_t pc = start[k] / kPiece; pc <= (start[k] + jobs[k].bytes - 1) / kPiece; pc++)
+            if (!done[pc].load(std::memory_order_acquire)) return false;
+        return true;
+    }
+    void run(unsigned nt)
+    {
+        for (unsigned t = 0; t < nt; t++)
+            th.emplace_back([this]() {
+                bool dev_set = false;
+                for (;;) {
+                    const size_t pc = next_piece.fetch_add(1);
+                    if (pc >= n_pieces) break;
+                    const size_t a = pc * kPiece, b = a + kPiece < total ? a + kPiece : total;
+                    touch(a, b);
+                    done[pc].store(1, std::memory_order_release);
+                    // whoever completes an array's pages page-locks it (2 ms per 0.8 GB once the pages exist; 33 ms
+                    // when they do not): the copy into it is then one DMA at the link's rate instead of the
+                    // runtime's staged copy (57 against 49 GB/s, scripts/probes/pcie_probe2.py)
+                    for (size_t k = 0; k < jobs.size(); k++) {
+                        if (start[k] + jobs[k].bytes <= a || start[k] >= b) continue;
+                        int expect = 0;
+                        if (job_pages_there(k) && reg[k].compare_exchange_strong(expect, 1)) {
+                            if (!dev_set) { (void)hipSetDevice(device); dev_set = true; }
+                            const bool ok = jobs[k].bytes > 0 && hipHostRegister(jobs[k].dst, jobs[k].bytes, hipHostRegisterDefault) == hipSuccess;
+                            if (!ok) (void)hipGetLastError();
+                            reg[k].store(ok ? 2 : 3, std::memory_order_release);
+                        }
                     }
                 }
             });
+    }
+    void wait_piece(size_t pc) { while (!done[pc].load(std::memory_order_acquire)) std::this_thread::yield(); }
+    int wait_registered(size_t k)
+    {
+        int v;
+        while ((v = reg[k].load(std::memory_order_acquire)) < 2) std::this_thread::yield();
+        return v;
+    }
+    ~OrderedPrefault()
+    {
+        for (auto& t : th) t.join();
+        for (size_t k = 0; k < jobs.size(); k++)
+            if (reg[k].load() == 2) (void)hipHostUnregister(jobs[k].dst);
+    }
+};
+}  // namespace
+
+// `ready`: called once before the first copy (waits for the kernel and may decide, from the status array, to
+// replace the jobs' sources -- the compaction of dropped rays); returns 0 or an error
+template <class Ready>
+static int d2h_pipelined(std::vector<D2HJob> jobs, hipStream_t st, int device, Ready ready)
+{
+    std::vector<D2HJob> whole;
+    std::vector<size_t> sub_of;
+    size_t total = 0;
+    for (auto& q : jobs) total += q.bytes;
+    if (total < ((size_t)32 << 20)) {    // small: not worth threads
+        int rc = ready(jobs);
+        if (rc) return rc;
+        for (auto& q : jobs) HIPCHK(hipMemcpyAsync(q.dst, q.src, q.bytes, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        return 0;
+    }
+    const double t0 = trace_now();
+    {   // arrays are cut into sub-jobs of <= 128 MB: the first one is faulted in and page-locked long before the kernel
+        // ends, and the copy stream never waits for a whole array's registration
+        std::vector<D2HJob> cut;
+        const size_t kSub = (size_t)128 << 20;
+        for (auto& q : jobs)
+            for (size_t o = 0; o < q.bytes; o += kSub)
+                cut.push_back({(char*)q.dst + o, (const char*)q.src + o, q.bytes - o < kSub ? q.bytes - o : kSub});
+        sub_of.clear();
+        for (size_t k = 0; k < jobs.size(); k++)
+            for (size_t o = 0; o < jobs[k].bytes; o += kSub) sub_of.push_back(k);
+        whole = jobs;
+        jobs = cut;
+    }
+    OrderedPrefault pf(jobs, device);
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt < 1 ? 1 : (nt > 16 ? 16 : nt);
+    pf.run(nt);
+    PGR_MARK(t0, "prefault threads started");
+    int rc = ready(whole);   // (sources may change and sizes shrink; the destinations stay)
+    if (rc) { HIPCHK(hipStreamSynchronize(st)); return rc; }
+    PGR_MARK(t0, "kernel finished, sources ready");
+    // the sub-jobs of the (possibly re-sourced, shortened) arrays
+    std::vector<D2HJob> live = jobs;
+    {
+        std::vector<size_t> seen(whole.size(), 0);
+        for (size_t j = 0; j < live.size(); j++) {
+            const size_t k = sub_of[j], o = seen[k];
+            seen[k] += jobs[j].bytes;
+            live[j].src = (const char*)whole[k].src + o;
+            live[j].bytes = o >= whole[k].bytes ? 0 : (whole[k].bytes - o < jobs[j].bytes ? whole[k].bytes - o : jobs[j].bytes);
         }
     }
-    for (auto& t : th) t.join();
+    for (size_t k = 0; k < live.size(); k++) {
+        const D2HJob& q = live[k];
+        if (q.bytes == 0) continue;
+        // pages there but not page-locked yet (locking is slow while the helper threads still fault pages in): do not
+        // wait for it -- claim the sub-job and copy it the staged way (49 GB/s instead of 57, but now)
+        for (size_t pc = pf.start[k] / OrderedPrefault::kPiece; pc <= (pf.start[k] + pf.jobs[k].bytes - 1) / OrderedPrefault::kPiece; pc++)
+            pf.wait_piece(pc);
+        int expect = 0;
+        if (pf.reg[k].compare_exchange_strong(expect, 4)) {
+            HIPCHK(hipMemcpyAsync(q.dst, q.src, q.bytes, hipMemcpyDeviceToHost, st));
+            if (trace_on() && (k == 0 || k + 1 == live.size()))
+                fprintf(stderr, "[pgr] %8.2f ms  sub-job %zu of %zu: %zu MB, staged copy, returned\n", trace_now() - t0, k, live.size(), q.bytes >> 20);
+            continue;
+        }
+        if (pf.wait_registered(k) == 2) {
+            HIPCHK(hipMemcpyAsync(q.dst, q.src, q.bytes, hipMemcpyDeviceToHost, st));   // one DMA into page-locked memory
+            if (trace_on() && (k == 0 || k + 1 == live.size()))
+                fprintf(stderr, "[pgr] %8.2f ms  sub-job %zu of %zu: %zu MB into registered memory, enqueued\n", trace_now() - t0, k, live.size(), q.bytes >> 20);
+            continue;
+        }
+        // page-locking failed (limits): staged copies, piece by piece as the pages arrive
+        size_t o = 0;
+        while (o < q.bytes) {
+            const size_t a = pf.start[k] + o;
+            size_t n = ((a / OrderedPrefault::kPiece) + 1) * OrderedPrefault::kPiece - a;
+            if (n > q.bytes - o) n = q.bytes - o;
+            pf.wait_piece(a / OrderedPrefault::kPiece);
+            HIPCHK(hipMemcpyAsync((char*)q.dst + o, (const char*)q.src + o, n, hipMemcpyDeviceToHost, st));
+            o += n;
+        }
+    }
+    PGR_MARK(t0, "all copies issued");
+    HIPCHK(hipStreamSynchronize(st));
+    PGR_MARK(t0, "all copies done");
+    return 0;
 }
 
 extern "C" int pgr_shoot_fan(pgr_env* env, const double* y0, int64_t N, double source_range,
@@ -948,7 +1153,11 @@ extern "C" int pgr_shoot_fan(pgr_env* env, const double* y0, int64_t N, double s
         dn1{(char*)env->ws + off[9]}, dn2{(char*)env->ws + off[10]};
     struct Trim {  // give a very large workspace (> 16 GB of the 288 GB) back when the call ends
         pgr_env* e;
-        ~Trim() { if (e->ws_bytes > ((size_t)16 << 30)) { (void)hipFree(e->ws); e->ws = nullptr; e->ws_bytes = 0; } }
+        ~Trim()
+        {
+            if (e->ws_bytes > ((size_t)16 << 30)) { (void)hipFree(e->ws); e->ws = nullptr; e->ws_bytes = 0; }
+            if (e->ws2_bytes > ((size_t)16 << 30)) { (void)hipFree(e->ws2); e->ws2 = nullptr; e->ws2_bytes = 0; }
+        }
     } trim{env};
     // everything of this call goes through the environment's own stream and waits for THAT stream only
     // (not the device: other streams of the process -- another environment's fan, a framework's copies --
@@ -977,46 +1186,47 @@ extern "C" int pgr_shoot_fan(pgr_env* env, const double* y0, int64_t N, double s
                                   (int32_t*)dns.p, (int32_t*)dst.p, (int32_t*)dn1.p, (int32_t*)dn2.p,
                                   (void*)st);
     if (rc) return rc;
-    // While the kernel runs: fault in the caller's (typically fresh, untouched) output buffers on
-    // several threads.  A D2H copy into untouched pageable memory runs at the page-fault rate of
-    // one thread (15 GB/s measured), into touched memory at 56 GB/s (scripts/probes/pcie_probe.py).
-    if (save && ns_bytes >= ((size_t)32 << 20)) prefault_outputs({T, z, p}, ns_bytes);
-    HIPCHK(hipStreamSynchronize(st));
-    HIPCHK(hipMemcpyAsync(status, dst.p, N * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    bool squeezed = false;
-    if (save && (flags & PGR_COMPACT)) {
+    // The per-ray arrays are small; the trajectories go out through the pipelined copy (page faults of the caller's
+    // -- typically fresh -- buffers in order on helper threads, starting now, while the kernel runs; copies as soon as
+    // the kernel is done and a piece's pages are there).  PGR_COMPACT: dropped rays are squeezed out on the device
+    // first ([S][N] -> [S][M], one pass at HBM speed into a second grow-only workspace).
+    std::vector<D2HJob> jobs;
+    if (save) jobs = {{T, dT.p, ns_bytes}, {z, dZ.p, ns_bytes}, {p, dP.p, ns_bytes}};
+    std::vector<int> keep;   // (outlives the asynchronous upload of the index list)
+    auto ready = [&](std::vector<D2HJob>& jb) -> int {
+        HIPCHK(hipMemcpyAsync(status, dst.p, N * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));       // the kernel has finished
+        if (!(save && (flags & PGR_COMPACT))) return 0;
         if (!(flags & PGR_SAMPLE_MAJOR)) return fail("pgr_shoot_fan: PGR_COMPACT needs PGR_SAMPLE_MAJOR");
         if (N > 0x7fffffff) return fail("pgr_shoot_fan: PGR_COMPACT supports at most 2^31 rays per call");
-        std::vector<int> keep;
         keep.reserve((size_t)N);
         for (int64_t k = 0; k < N; k++) if (status[k] == 0) keep.push_back((int)k);
         const int64_t M = (int64_t)keep.size();
-        if (M < N) {
-            // dropped rays leave the trajectories on the device: [S][N] -> [S][M], then one linear copy
-            squeezed = true;
-            struct Buf { void* p = nullptr; ~Buf() { if (p) (void)hipFree(p); } } tmp, didx;
-            if (M > 0) {
-                HIPCHK(hipMalloc(&tmp.p, (size_t)S * (size_t)M * sizeof(double)));
-                HIPCHK(hipMalloc(&didx.p, (size_t)M * sizeof(int)));
-                HIPCHK(hipMemcpyAsync(didx.p, keep.data(), (size_t)M * sizeof(int), hipMemcpyHostToDevice, st));
-                double* host[3] = {T, z, p};
-                void* dev[3] = {dT.p, dZ.p, dP.p};
-                for (int a3 = 0; a3 < 3; a3++) {
-                    hipLaunchKernelGGL(pgr_gather_cols, dim3((unsigned)((M + 255) / 256), (unsigned)S), dim3(256), 0,
-                                       st, (const double*)dev[a3], (double*)tmp.p, (const int*)didx.p, M, N);
-                    HIPCHK(hipGetLastError());
-                    HIPCHK(hipMemcpyAsync(host[a3], tmp.p, (size_t)S * (size_t)M * sizeof(double), hipMemcpyDeviceToHost, st));
-                    HIPCHK(hipStreamSynchronize(st));  // tmp is reused by the next array
-                }
+        if (M == N) return 0;
+        const size_t mbytes = (size_t)S * (size_t)M * sizeof(double), piece = (mbytes + 255) & ~(size_t)255;
+        const size_t need2 = 3 * piece + (((size_t)M * 4 + 255) & ~(size_t)255) + 256;
+        if (need2 > env->ws2_bytes) {
+            if (env->ws2) (void)hipFree(env->ws2);
+            env->ws2 = nullptr; env->ws2_bytes = 0;
+            if (hipMalloc(&env->ws2, need2) != hipSuccess) { env->ws2 = nullptr; return fail("pgr_shoot_fan: device allocation failed"); }
+            env->ws2_bytes = need2;
+        }
+        int* didx = (int*)((char*)env->ws2 + 3 * piece);
+        if (M > 0) {
+            HIPCHK(hipMemcpyAsync(didx, keep.data(), (size_t)M * sizeof(int), hipMemcpyHostToDevice, st));
+            for (int a3 = 0; a3 < 3; a3++) {
+                double* tmp = (double*)((char*)env->ws2 + (size_t)a3 * piece);
+                hipLaunchKernelGGL(pgr_gather_cols, dim3((unsigned)((M + 255) / 256), (unsigned)S), dim3(256), 0, st,
+                                   (const double*)jb[a3].src, tmp, (const int*)didx, M, N);
+                HIPCHK(hipGetLastError());
+                jb[a3].src = tmp;
             }
         }
-    }
-    if (save && !squeezed) {
-        HIPCHK(hipMemcpyAsync(T, dT.p, ns_bytes, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(z, dZ.p, ns_bytes, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(p, dP.p, ns_bytes, hipMemcpyDeviceToHost, st));
-    }
+        for (int a3 = 0; a3 < 3; a3++) jb[a3].bytes = mbytes;
+        return 0;
+    };
+    rc = d2h_pipelined(jobs, st, env->device, ready);
+    if (rc) return rc;
     if (end_state) HIPCHK(hipMemcpyAsync(end_state, dE.p, N * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(n_bott, dnb.p, N * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(n_surf, dns.p, N * 4, hipMemcpyDeviceToHost, st));
@@ -1024,6 +1234,233 @@ extern "C" int pgr_shoot_fan(pgr_env* env, const double* y0, int64_t N, double s
     if (n_rej) HIPCHK(hipMemcpyAsync(n_rej, dn2.p, N * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// Initial states on the device: y0 = [0, source_depth, sin(radians(angle)) / c_source] per ray
+// (REF/launch_rays.py:140-144, 284-285), the sine correctly rounded (pgr_crmath.h) -- the same arithmetic
+// pgr_eigen_step uses for its trial rays.  A million-ray fan saves the host's 1e6 libm sines and the upload of y0.
+// ------------------------------------------------------------------------------------
+__global__ void pgr_y0_kernel(const double* __restrict__ ang_deg, int64_t N, double source_depth, double c_source,
+                              double* __restrict__ y0)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    y0[3 * k + 0] = 0.0;
+    y0[3 * k + 1] = source_depth;
+    y0[3 * k + 2] = pgr_cr_sin(ang_deg[k] * (M_PI / 180.0)) / c_source;
+}
+
+extern "C" int pgr_initial_states_device(int device, const double* ode_angles_deg, int64_t N, double source_depth,
+                                         double c_source, double* y0, void* stream)
+{
+    if (N < 0 || (N > 0 && (!ode_angles_deg || !y0))) return fail("pgr_initial_states_device: bad argument");
+    if (!(c_source > 0)) return fail("pgr_initial_states_device: c_source must be positive");
+    if (N == 0) return 0;
+    HIPCHK(hipSetDevice(device));
+    hipLaunchKernelGGL(pgr_y0_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ode_angles_deg, N,
+                       source_depth, c_source, y0);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// A fan whose results stay in HBM (pgr_fan_*): launch, come back at once, fetch what is wanted when it is
+// wanted.  pygenray hands its caller a RayFan of host arrays (REF/launch_rays.py:166-186); most callers then read a
+// few columns of it (find_eigenrays: the end depths, REF/eigenrays.py:65-79) -- the 2.4 GB of a 1e5 x 1001 fan cross
+// PCIe (43 ms, 8x the kernel) only if somebody asks for them.
+// ------------------------------------------------------------------------------------
+struct pgr_fan {
+    pgr_env* env = nullptr;
+    int64_t N = 0, M = -1;
+    int32_t S = 0;
+    uint32_t flags = 0;
+    bool save = false, finished = false;
+    void* buf = nullptr;
+    size_t buf_bytes = 0;
+    double *y0 = nullptr, *r = nullptr, *T = nullptr, *Z = nullptr, *P = nullptr, *end = nullptr;
+    int32_t *nb = nullptr, *ns = nullptr, *st = nullptr, *n1 = nullptr, *n2 = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    std::vector<int32_t> status_host;
+    std::vector<int> keep;
+    std::mutex m;
+};
+
+extern "C" void pgr_fan_destroy(pgr_fan* f)
+{
+    if (!f) return;
+    (void)hipSetDevice(f->env->device);
+    if (f->done) { (void)hipEventSynchronize(f->done); (void)hipEventDestroy(f->done); }
+    if (f->buf) {
+        std::lock_guard<std::mutex> lock(f->env->fan_pool_mutex);
+        size_t held = 0;
+        for (auto& pb : f->env->fan_pool) held += pb.second;
+        if (f->env->fan_pool.size() < 4 && held + f->buf_bytes <= ((size_t)64 << 30)) f->env->fan_pool.emplace_back(f->buf, f->buf_bytes);
+        else (void)hipFree(f->buf);
+    }
+    delete f;
+}
+
+extern "C" int pgr_fan_launch(pgr_env* env, const double* y0, const double* ode_angles_deg, double source_depth,
+                              double c_source, int64_t N, double source_range, double receiver_range, int32_t S,
+                              double rtol, double atol, uint32_t flags, int64_t max_steps, pgr_fan** out)
+{
+    if (!env || !out) return fail("pgr_fan_launch: null argument");
+    *out = nullptr;
+    const double t0 = trace_now();
+    if (N <= 0) return fail("pgr_fan_launch: need at least one ray");
+    if (!y0 && !ode_angles_deg) return fail("pgr_fan_launch: give y0 or launch angles");
+    if (S < 0) return fail("pgr_fan_launch: negative num_range_save");
+    HIPCHK(hipSetDevice(env->device));
+    if (!env->stream) {
+        std::lock_guard<std::mutex> lock(env->ws_mutex);
+        if (!env->stream) HIPCHK(hipStreamCreateWithFlags(&env->stream, hipStreamNonBlocking));
+    }
+    pgr_fan* f = new pgr_fan();
+    f->env = env; f->N = N; f->S = S; f->save = (S > 0);
+    f->flags = (flags & ~(uint32_t)(PGR_COMPACT | PGR_PACKED_END)) | PGR_SAMPLE_MAJOR | PGR_SAVE_LINSPACE;
+    f->stream = env->stream;
+    const size_t ns_bytes = (size_t)N * (size_t)S * sizeof(double);
+    const size_t sizes[11] = {(size_t)N * 24, (size_t)(S > 0 ? S : 1) * 8, ns_bytes, ns_bytes, ns_bytes, (size_t)N * 24,
+                              (size_t)N * 4, (size_t)N * 4, (size_t)N * 4, (size_t)N * 4, (size_t)N * 4};
+    size_t off[11], total = 0;
+    for (int k = 0; k < 11; k++) { off[k] = total; total += (sizes[k] + 255) & ~(size_t)255; }
+    {   // the smallest pooled buffer that fits (and is not more than twice too large), else a fresh one
+        std::lock_guard<std::mutex> lock(env->fan_pool_mutex);
+        int best = -1;
+        for (size_t k = 0; k < env->fan_pool.size(); k++)
+            if (env->fan_pool[k].second >= total && env->fan_pool[k].second <= 2 * total + ((size_t)1 << 20) &&
+                (best < 0 || env->fan_pool[k].second < env->fan_pool[(size_t)best].second)) best = (int)k;
+        if (best >= 0) {
+            f->buf = env->fan_pool[(size_t)best].first; f->buf_bytes = env->fan_pool[(size_t)best].second;
+            env->fan_pool.erase(env->fan_pool.begin() + best);
+        }
+    }
+    if (!f->buf) {
+        if (hipMalloc(&f->buf, total) != hipSuccess) { f->buf = nullptr; pgr_fan_destroy(f); return fail("pgr_fan_launch: device allocation failed"); }
+        f->buf_bytes = total;
+    }
+    char* b = (char*)f->buf;
+    f->y0 = (double*)(b + off[0]); f->r = (double*)(b + off[1]); f->T = (double*)(b + off[2]); f->Z = (double*)(b + off[3]);
+    f->P = (double*)(b + off[4]); f->end = (double*)(b + off[5]); f->nb = (int32_t*)(b + off[6]); f->ns = (int32_t*)(b + off[7]);
+    f->st = (int32_t*)(b + off[8]); f->n1 = (int32_t*)(b + off[9]); f->n2 = (int32_t*)(b + off[10]);
+    hipStream_t st = f->stream;
+    hipEvent_t up = nullptr;
+    int rc = 0;
+    do {
+        if (hipEventCreateWithFlags(&f->done, hipEventDisableTiming) != hipSuccess) { rc = fail("pgr_fan_launch: event"); break; }
+        if (y0) {
+            if (hipMemcpyAsync(f->y0, y0, (size_t)N * 24, hipMemcpyHostToDevice, st) != hipSuccess) { rc = fail("pgr_fan_launch: upload of y0"); break; }
+        } else {
+            // the angles ride in the (not yet used) end_state array; y0 is computed on the device
+            if (hipMemcpyAsync(f->end, ode_angles_deg, (size_t)N * 8, hipMemcpyHostToDevice, st) != hipSuccess) { rc = fail("pgr_fan_launch: upload of the angles"); break; }
+            rc = pgr_initial_states_device(env->device, f->end, N, source_depth, c_source, f->y0, (void*)st);
+            if (rc) break;
+        }
+        if (hipEventCreateWithFlags(&up, hipEventDisableTiming) != hipSuccess || hipEventRecord(up, st) != hipSuccess) { rc = fail("pgr_fan_launch: event"); break; }
+        rc = pgr_shoot_fan_device(env, f->y0, N, source_range, receiver_range, f->r, S > 0 ? S : 1, rtol, atol, f->flags, max_steps,
+                                  f->save ? f->T : nullptr, f->save ? f->Z : nullptr, f->save ? f->P : nullptr, f->end,
+                                  f->nb, f->ns, f->st, f->n1, f->n2, (void*)st);
+        if (rc) break;
+        if (hipEventRecord(f->done, st) != hipSuccess) { rc = fail("pgr_fan_launch: event record"); break; }
+        // the caller may release y0 / the angles when this returns: wait for the upload (not for the kernel behind it)
+        if (hipEventSynchronize(up) != hipSuccess) { rc = fail("pgr_fan_launch: upload"); break; }
+    } while (0);
+    if (up) (void)hipEventDestroy(up);
+    if (rc) { pgr_fan_destroy(f); return rc; }
+    *out = f;
+    PGR_MARK(t0, "pgr_fan_launch: enqueued, upload done");
+    return 0;
+}
+
+// waits for the kernel, reads the status array back once and counts the surviving rays
+static int fan_finish(pgr_fan* f)
+{
+    if (f->finished) return 0;
+    HIPCHK(hipSetDevice(f->env->device));
+    HIPCHK(hipEventSynchronize(f->done));
+    f->status_host.resize((size_t)f->N);
+    HIPCHK(hipMemcpy(f->status_host.data(), f->st, (size_t)f->N * 4, hipMemcpyDeviceToHost));
+    f->keep.clear();
+    for (int64_t k = 0; k < f->N; k++) if (f->status_host[(size_t)k] == 0) f->keep.push_back((int)k);
+    f->M = (int64_t)f->keep.size();
+    f->finished = true;
+    return 0;
+}
+
+extern "C" int pgr_fan_wait(pgr_fan* f, int64_t* n_rays, int64_t* n_ok)
+{
+    if (!f) return fail("pgr_fan_wait: null fan");
+    std::lock_guard<std::mutex> lock(f->m);
+    int rc = fan_finish(f);
+    if (rc) return rc;
+    if (n_rays) *n_rays = f->N;
+    if (n_ok) *n_ok = f->M;
+    return 0;
+}
+
+extern "C" int pgr_fan_fetch_rays(pgr_fan* f, double* end_state, int32_t* n_bott, int32_t* n_surf, int32_t* status,
+                                  int32_t* n_steps, int32_t* n_rej)
+{
+    if (!f) return fail("pgr_fan_fetch_rays: null fan");
+    std::lock_guard<std::mutex> lock(f->m);
+    const double t0 = trace_now();
+    int rc = fan_finish(f);
+    if (rc) return rc;
+    PGR_MARK(t0, "pgr_fan_fetch_rays: kernel finished, status on the host");
+    const size_t n = (size_t)f->N;
+    if (end_state) HIPCHK(hipMemcpy(end_state, f->end, n * 24, hipMemcpyDeviceToHost));
+    if (n_bott) HIPCHK(hipMemcpy(n_bott, f->nb, n * 4, hipMemcpyDeviceToHost));
+    if (n_surf) HIPCHK(hipMemcpy(n_surf, f->ns, n * 4, hipMemcpyDeviceToHost));
+    if (status) memcpy(status, f->status_host.data(), n * 4);
+    if (n_steps) HIPCHK(hipMemcpy(n_steps, f->n1, n * 4, hipMemcpyDeviceToHost));
+    if (n_rej) HIPCHK(hipMemcpy(n_rej, f->n2, n * 4, hipMemcpyDeviceToHost));
+    PGR_MARK(t0, "pgr_fan_fetch_rays: done");
+    return 0;
+}
+
+extern "C" int pgr_fan_fetch_samples(pgr_fan* f, double* T, double* z, double* p, uint32_t flags)
+{
+    if (!f) return fail("pgr_fan_fetch_samples: null fan");
+    if (!f->save) return fail("pgr_fan_fetch_samples: the fan was launched without trajectories (S = 0)");
+    std::lock_guard<std::mutex> lock(f->m);
+    HIPCHK(hipSetDevice(f->env->device));
+    const bool compact = (flags & PGR_COMPACT) != 0;
+    const size_t ns_bytes = (size_t)f->N * (size_t)f->S * sizeof(double);
+    std::vector<D2HJob> jobs;
+    std::vector<const double*> src;
+    if (T) { jobs.push_back({T, f->T, ns_bytes}); src.push_back(f->T); }
+    if (z) { jobs.push_back({z, f->Z, ns_bytes}); src.push_back(f->Z); }
+    if (p) { jobs.push_back({p, f->P, ns_bytes}); src.push_back(f->P); }
+    if (jobs.empty()) return 0;
+    struct Tmp { std::vector<void*> p; ~Tmp() { for (void* q : p) if (q) (void)hipFree(q); } } tmp;
+    hipStream_t st = f->stream;
+    auto ready = [&](std::vector<D2HJob>& jb) -> int {
+        int rc = fan_finish(f);
+        if (rc) return rc;
+        if (!compact || f->M == f->N) return 0;
+        const int64_t M = f->M;
+        const size_t mbytes = (size_t)f->S * (size_t)M * sizeof(double);
+        if (M > 0) {
+            void* didx = nullptr;
+            HIPCHK(hipMalloc(&didx, (size_t)M * sizeof(int)));
+            tmp.p.push_back(didx);
+            HIPCHK(hipMemcpyAsync(didx, f->keep.data(), (size_t)M * sizeof(int), hipMemcpyHostToDevice, st));
+            for (size_t a3 = 0; a3 < jb.size(); a3++) {
+                void* t = nullptr;
+                HIPCHK(hipMalloc(&t, mbytes));
+                tmp.p.push_back(t);
+                hipLaunchKernelGGL(pgr_gather_cols, dim3((unsigned)((M + 255) / 256), (unsigned)f->S), dim3(256), 0, st,
+                                   (const double*)jb[a3].src, (double*)t, (const int*)didx, M, f->N);
+                HIPCHK(hipGetLastError());
+                jb[a3].src = t;
+            }
+        }
+        for (auto& q : jb) q.bytes = mbytes;
+        return 0;
+    };
+    return d2h_pipelined(jobs, st, f->env->device, ready);
 }
 
 // ------------------------------------------------------------------------------------

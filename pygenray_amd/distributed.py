@@ -103,11 +103,12 @@ def shoot_fan_sharded(compute, y0_all, group=None):
 def hip_compute(env_handle, source_range, receiver_range, rtol=1e-9, atol=1e-6,
                 terminate_backwards=True, max_steps=1_000_000):
     """End-state-only HIP fan as a `compute` callback for ``shoot_fan_sharded``."""
-    from .device_fan import DeviceFan
+    from .device_fan import cached_end_state_fan
 
     def compute(y0_local):
-        fan = DeviceFan(env_handle, y0_local, source_range, receiver_range, 1, rtol=rtol, atol=atol,
-                        terminate_backwards=terminate_backwards, save=False, max_steps=max_steps)
+        # (one set of device buffers per environment handle, grow-only: no allocation per fan)
+        fan = cached_end_state_fan(env_handle, y0_local, source_range, receiver_range, rtol=rtol, atol=atol,
+                                   terminate_backwards=terminate_backwards, max_steps=max_steps)
         fan.run()
         return fan.end, fan.n_bott, fan.n_surf, fan.status
     return compute
@@ -310,7 +311,7 @@ def arrival_histogram_sharded(source_depth, source_range, launch_angles, receive
         compute = hip_end_state_compute(environment, flatearth, rtol=rtol, terminate_backwards=terminate_backwards,
                                         device=device)
     records = compute(y0, x0, x1, backwards, len(idx))
-    ints = records[:, 3:5].view(torch.int32) if records.is_cuda else records[:, 3:5].contiguous().view(torch.int32)
+    ints = records[:, 3:5].view(torch.int32)
     h = arrival_time_histogram(records[:len(idx), 0], ints[:len(idx), 2], bins, t_min, t_max, group=group, reduce=True)
     return h.cpu().numpy(), np.linspace(float(t_min), float(t_max), int(bins) + 1)
 

@@ -52,13 +52,22 @@ def _regula_falsi_batch(z1, z2, th1, th2, receiver_depth, source_depth, source_r
     r = np.linspace(source_range, receiver_range, S)
     if found.any():
         idx = np.where(found)[0]
-        # the eigenrays themselves, with trajectories: shoot_ray(theta), ODE angle = -theta (REF/launch_rays.py:251)
-        fin = _shoot_ode_angles(source_depth, source_range, -th_found[idx], receiver_range, S, environment, rtol,
-                                terminate_backwards, flatearth, device=device)
+        # the eigenrays themselves, with trajectories: shoot_ray(theta), ODE angle = -theta (REF/launch_rays.py:251), from
+        # the SAME initial state as the trial ray the search accepted -- computed on the device from the angle with the
+        # correctly rounded sine, as pgr_eigen_step did -- so the ray returned IS the accepted one
+        from .launch_rays import _launch_device_fan
+        h, r = _launch_device_fan(source_depth, source_range, -th_found[idx], receiver_range, S, environment, rtol,
+                                  terminate_backwards, flatearth, device=device, stored_sign=True, device_y0=True)
         LAST_SEARCH_STATS["launches"] += 1
-        r = fin["r"]
-        T[idx], Z[idx], P[idx] = fin["T"], -fin["z"], -fin["p"]
-        nb[idx], ns[idx] = fin["n_bott"], fin["n_surf"]
+        rays = h.fetch_rays()
+        smp = h.fetch_samples(("T", "z", "p"), compact=False)
+        h.close()
+        if not np.all(rays["status"] == 0) or not np.all(np.abs(-rays["end"][:, 1] + receiver_depth) < ztol):
+            raise RuntimeError("find_eigenrays: a re-shot eigenray differs from the trial ray the search accepted")
+        if not np.array_equal(-rays["end"][:, 1], out["z_end"][idx]):
+            raise RuntimeError("find_eigenrays: a re-shot eigenray does not end where its trial ray did")
+        T[idx], Z[idx], P[idx] = smp["T"].T, smp["z"].T, smp["p"].T
+        nb[idx], ns[idx] = rays["n_bott"], rays["n_surf"]
     return found, th_found, r, T, Z, P, nb, ns
 
 
@@ -66,9 +75,10 @@ def _bracket(rays, receiver_depth):
     """Brackets of one receiver depth on the WHOLE fan, exactly as REF/eigenrays.py:65-79: sign changes of
     z_end + receiver_depth between neighbouring fan rays (dropped rays have vanished from the fan, Q12, so a
     bracket may span one)."""
-    depth_sign = np.sign(rays.zs[:, -1] + receiver_depth)
+    z_end = rays.zs_end if hasattr(rays, "zs_end") else rays.zs[:, -1]   # (a device-resident fan keeps its trajectories in HBM)
+    depth_sign = np.sign(z_end + receiver_depth)
     starts = np.where(np.diff(depth_sign))[0]
-    return starts, rays.zs[starts, -1], rays.zs[starts + 1, -1], rays.thetas[starts], rays.thetas[starts + 1]
+    return starts, z_end[starts], z_end[starts + 1], rays.thetas[starts], rays.thetas[starts + 1]
 
 
 def _find_eigenrays(rays, receiver_depths, source_depth, num_range_save, environment, refine):

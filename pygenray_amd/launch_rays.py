@@ -61,7 +61,7 @@ def _shoot_ode_angles(source_depth, source_range, ode_angles_deg, receiver_range
     ang = np.asarray(ode_angles_deg, dtype=float).reshape(-1)
     y0 = np.zeros((len(ang), 3))
     y0[:, 1] = source_depth
-    y0[:, 2] = np.sin(np.radians(ang)) / c
+    y0[:, 2] = _initial_slowness(ang, c)
     if not (source_range_i < receiver_range_i):
         # the reference's bounce loop never runs and _interpolate_ray indexes an empty list
         raise IndexError("list index out of range")
@@ -77,6 +77,50 @@ def _shoot_ode_angles(source_depth, source_range, ode_angles_deg, receiver_range
     return out
 
 
+def _initial_slowness(ode_angles_deg, c):
+    """sin(radians(theta)) / c per ray (REF/launch_rays.py:140-144) with NumPy's own sine; a million-angle fan
+    splits the (GIL-free) ufunc calls over a few threads -- the same routine on every element, the same bits."""
+    ang = np.asarray(ode_angles_deg, dtype=float).reshape(-1)
+    if len(ang) < 400_000:
+        return np.sin(np.radians(ang)) / c
+    from concurrent.futures import ThreadPoolExecutor
+    out = np.empty(len(ang))
+    nt = 8
+    per = (len(ang) + nt - 1) // nt
+
+    def part(k):
+        sl = slice(k * per, (k + 1) * per)
+        np.divide(np.sin(np.radians(ang[sl])), c, out=out[sl])
+    with ThreadPoolExecutor(nt) as ex:
+        list(ex.map(part, range(nt)))
+    return out
+
+
+def _launch_device_fan(source_depth, source_range, ode_angles_deg, receiver_range, num_range_save, environment, rtol,
+                       terminate_backwards, flatearth, device=0, max_steps=1_000_000, stored_sign=True,
+                       device_y0=False):
+    """The fan of _shoot_ode_angles launched device-resident (``_lib.FanHandle``): returns (handle, r) while the kernel
+    runs.  ``device_y0``: the initial states are computed on the device from the angles (correctly rounded sine: what
+    the eigenray refinement's trial rays use) instead of uploaded."""
+    backwards = receiver_range < source_range
+    env, (cin, rin, zin) = _device_env(environment, flatearth, backwards, device)
+    x0, x1 = (-source_range, -receiver_range) if backwards else (source_range, receiver_range)
+    if not (x0 < x1):
+        raise IndexError("list index out of range")
+    c = bilinear_interp(x0, source_depth, rin, zin, cin)
+    ang = np.asarray(ode_angles_deg, dtype=float).reshape(-1)
+    kw = dict(rtol=rtol, terminate_backwards=terminate_backwards, max_steps=max_steps, stored_sign=stored_sign)
+    if device_y0:
+        h = _lib.FanHandle(env, x0, x1, num_range_save, ode_angles_deg=ang, source_depth=source_depth, c_source=c, **kw)
+    else:
+        y0 = np.zeros((len(ang), 3))
+        y0[:, 1] = source_depth
+        y0[:, 2] = _initial_slowness(ang, c)
+        h = _lib.FanHandle(env, x0, x1, num_range_save, y0=y0, **kw)
+    r = np.linspace(x0, x1, int(num_range_save))
+    return h, (-r if backwards else r)
+
+
 def _report_drops(status, debug):
     if debug:
         for s in status[status != 0]:
@@ -85,13 +129,18 @@ def _report_drops(status, debug):
 
 def shoot_rays(source_depth, source_range, launch_angles, receiver_range, num_range_save,
                environment, rtol=1e-9, terminate_backwards=True, n_processes=None, debug=True,
-               flatearth=True, device=0):
+               flatearth=True, device=0, device_resident=None):
     """Integrate a fan of rays (REF/launch_rays.py:11-200) -> ``RayFan``.
 
     ``n_processes`` is accepted for compatibility and ignored (the fan is one GPU launch).
     Launch-angle sign: like the reference, a fan of fewer than 70 angles is integrated with
     ODE angle = +user angle and a larger fan with ODE angle = -user angle (Q1 in SURVEY.md:
-    REF/launch_rays.py:67,94,251); dropped rays vanish from the fan (Q12)."""
+    REF/launch_rays.py:67,94,251); dropped rays vanish from the fan (Q12).
+
+    ``device_resident`` (not a reference argument): True -- the call returns when the kernel has finished and the
+    per-ray arrays are on the host; the fan's ``ts`` / ``zs`` / ``ps`` stay in HBM and cross PCIe when they are first
+    read (``RayFan.from_device``; same values, same shapes); False -- everything is copied before the call returns;
+    None (default) -- device resident from 2 million samples per array on (a 1e5 x 1001 fan: 7 ms instead of 50)."""
     if type(launch_angles) is list:
         launch_angles = np.array(launch_angles)
     launch_angles = -np.asarray(launch_angles, dtype=float)
@@ -102,6 +151,17 @@ def shoot_rays(source_depth, source_range, launch_angles, receiver_range, num_ra
     else:
         ode = launch_angles
         stored = -launch_angles  # REF/launch_rays.py:180
+    if device_resident is None:
+        device_resident = n * int(num_range_save) >= 2_000_000
+    if device_resident and n > 0:
+        h, r = _launch_device_fan(source_depth, source_range, ode, receiver_range, num_range_save, environment, rtol,
+                                  terminate_backwards, flatearth, device=device, stored_sign=True)
+        rays = h.fetch_rays()                       # waits for the kernel; the small per-ray arrays only
+        _report_drops(rays["status"], debug)
+        keep = rays["status"] == 0
+        M = int(keep.sum())
+        return RayFan.from_device(h, stored[keep], r, rays["end"][keep], rays["n_bott"][keep].astype(np.int64),
+                                  rays["n_surf"][keep].astype(np.int64), np.full(M, source_depth))
     # stored convention z -> -z, p -> -p (REF/ray_objects.py:51-52) applied by the kernel's stores
     out = _shoot_ode_angles(source_depth, source_range, ode, receiver_range, num_range_save,
                             environment, rtol, terminate_backwards, flatearth, device=device,

@@ -59,6 +59,82 @@ class RayFan:
         self._ray_ids = None  # built on first access (a million-ray fan pays 0.2 s for the strings)
         return self
 
+    @classmethod
+    def from_device(cls, handle, thetas, r, end, n_botts, n_surfs, source_depths):
+        """A fan whose trajectories are still in HBM (``_lib.FanHandle``, launched with the stored sign convention):
+        ``ts`` / ``zs`` / ``ps`` cross PCIe when they are first read -- each on its own, dropped rays already squeezed
+        out on the device -- and are ordinary (M, S) arrays from then on; ``rs`` is a broadcast view of the save grid.
+        The per-ray arrays and the end states (``ts_end``, ``zs_end``, ``ps_end``: the last column, what
+        ``find_eigenrays`` brackets on, REF/eigenrays.py:65-79) are on the host from the start.  `end` is the
+        ODE-convention end state of the surviving rays."""
+        self = cls.__new__(cls)
+        self.thetas = np.asarray(thetas)
+        self._dev = handle
+        self._r = np.asarray(r)
+        self._end = np.asarray(end)
+        self.n_botts = np.asarray(n_botts)
+        self.n_surfs = np.asarray(n_surfs)
+        self.source_depths = np.asarray(source_depths)
+        self._ray_ids = None
+        return self
+
+    # ts / zs / ps / rs: plain attributes for a host fan, fetched from the device on first access for a device fan
+    def _lazy(name, key):   # noqa: N805  (a property factory, not a method)
+        def get(self):
+            d = self.__dict__
+            if name not in d:
+                dev = d.get("_dev")
+                if dev is None:
+                    raise AttributeError(name[1:])
+                d[name] = dev.fetch_samples((key,), compact=True)[key].T     # (M, S) view of the [S][M] block
+                if all(k in d for k in ("_ts", "_zs", "_ps")):
+                    dev.close()             # everything is on the host: give the HBM back
+                    d["_dev"] = None
+            return d[name]
+
+        def set_(self, value):
+            self.__dict__[name] = value
+        return property(get, set_)
+
+    ts = _lazy("_ts", "T")
+    zs = _lazy("_zs", "z")
+    ps = _lazy("_ps", "p")
+    del _lazy
+
+    @property
+    def rs(self):
+        d = self.__dict__
+        if "_rs" not in d:
+            if d.get("_r") is None:
+                raise AttributeError("rs")
+            d["_rs"] = np.broadcast_to(d["_r"], (len(self.thetas), len(d["_r"])))
+        return d["_rs"]
+
+    @rs.setter
+    def rs(self, value):
+        self.__dict__["_rs"] = value
+
+    @property
+    def device_resident(self):
+        """True while some trajectory array has not been fetched from the GPU yet."""
+        return self.__dict__.get("_dev") is not None
+
+    # the state at receiver_range, stored convention, without touching the trajectories
+    @property
+    def ts_end(self):
+        e = self.__dict__.get("_end")
+        return e[:, 0] if e is not None else self.ts[:, -1]
+
+    @property
+    def zs_end(self):
+        e = self.__dict__.get("_end")
+        return -e[:, 1] if e is not None else self.zs[:, -1]
+
+    @property
+    def ps_end(self):
+        e = self.__dict__.get("_end")
+        return -e[:, 2] if e is not None else self.ps[:, -1]
+
     @property
     def ray_ids(self):
         if getattr(self, "_ray_ids", None) is None:

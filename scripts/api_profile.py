@@ -11,9 +11,11 @@ z = np.arange(0, 6000, 1.0); r = np.linspace(0, rmax, 100)
 env = pr.OceanEnvironment2D(pr.DataArray(np.tile(pr.munk_ssp(z), (100, 1)), dims=["range", "depth"], coords={"range": r, "depth": z}),
                             pr.DataArray(np.full(100, 5000.0), dims=["range"], coords={"range": r}), flat_earth_transform=False)
 angles = np.linspace(-20, 20, n)
-pr.shoot_rays(1000.0, 0.0, angles, rmax, S, env, debug=False, flatearth=False)
-p = cProfile.Profile(); p.enable(); t0 = time.perf_counter()
-fan = pr.shoot_rays(1000.0, 0.0, angles, rmax, S, env, debug=False, flatearth=False)
-dt = time.perf_counter() - t0; p.disable()
-print(f"shoot_rays({n}, S={S}): {dt*1e3:.1f} ms")
-pstats.Stats(p).sort_stats("tottime").print_stats(14)
+for mode in (False, True):
+    pr.shoot_rays(1000.0, 0.0, angles, rmax, S, env, debug=False, flatearth=False, device_resident=mode)
+    p = cProfile.Profile(); p.enable(); t0 = time.perf_counter()
+    fan = pr.shoot_rays(1000.0, 0.0, angles, rmax, S, env, debug=False, flatearth=False, device_resident=mode)
+    dt = time.perf_counter() - t0; p.disable()
+    print(f"shoot_rays({n}, S={S}, device_resident={mode}): {dt*1e3:.1f} ms")
+    pstats.Stats(p).sort_stats("tottime").print_stats(12)
+    del fan

@@ -774,6 +774,135 @@ def test_sharded_hip_compute_single_rank(lib):
     assert int(h.sum().item()) == int(((ref["status"] == 0) & (ref["end"][:, 0] >= 66) & (ref["end"][:, 0] <= 68)).sum())
 
 
+def test_sharded_api_single_rank_rccl_equals_the_single_process_api(lib):
+    """pygenray_amd.distributed's API over RCCL (backend "nccl") with ONE rank on this one-GPU box: the gathered
+    end-state fan equals the last column of pr.shoot_rays' fan, find_eigenrays_sharded equals pr.find_eigenrays
+    (same brackets, same eigenrays to the bit: both run pgr_eigen_refine), the all-reduced histogram equals
+    np.histogram.  (Two ranks, with brackets straddling them and a dropped ray inside a bracket: the gloo test in
+    tests/test_host.py.)"""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    import pygenray_amd as pr
+    from pygenray_amd.distributed import shoot_rays_sharded, find_eigenrays_sharded, arrival_histogram_sharded
+    z = np.arange(0, 6000, 1.0); r = np.linspace(0, 100e3, 100)
+    env = pr.OceanEnvironment2D(pr.DataArray(np.tile(pr.munk_ssp(z), (100, 1)), dims=["range", "depth"], coords={"range": r, "depth": z}),
+                                pr.DataArray(np.full(100, 5000.0), dims=["range"], coords={"range": r}), flat_earth_transform=False)
+    theta = np.linspace(-19.9, 19.9, 2001)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        fan = shoot_rays_sharded(1000.0, 0.0, theta, 100e3, env, flatearth=False)
+        again = shoot_rays_sharded(1000.0, 0.0, theta[::2], 100e3, env, flatearth=False)     # re-uses the cached buffers
+        er = find_eigenrays_sharded(fan, [800.0, 1000.0], 1000.0, 0.0, 100e3, 41, env, debug=False, flatearth=False, quiet=True)
+        h, edges = arrival_histogram_sharded(1000.0, 0.0, theta, 100e3, env, 64, 66.0, 68.0, flatearth=False)
+    finally:
+        dist.destroy_process_group()
+    ref = pr.shoot_rays(1000.0, 0.0, theta, 100e3, 3, env, debug=False, flatearth=False)
+    assert len(fan) == len(ref) and np.array_equal(fan.thetas, ref.thetas)
+    for a_, b_ in ((fan.ts, ref.ts), (fan.zs, ref.zs), (fan.ps, ref.ps)):
+        assert a_.shape == (len(ref), 1) and np.array_equal(a_[:, 0], b_[:, -1])
+    assert np.array_equal(fan.n_botts, ref.n_botts) and np.array_equal(fan.n_surfs, ref.n_surfs)
+    ref2 = pr.shoot_rays(1000.0, 0.0, theta[::2], 100e3, 3, env, debug=False, flatearth=False)
+    assert np.array_equal(again.thetas, ref2.thetas) and np.array_equal(again.zs[:, 0], ref2.zs[:, -1])
+    er1 = pr.find_eigenrays(ref, [800.0, 1000.0], 1000.0, 0.0, 100e3, 41, env, debug=False, flatearth=False, quiet=True)
+    for k in (0, 1):
+        assert er.num_eigenrays_found[k] == er1.num_eigenrays_found[k] >= 3
+        assert np.array_equal(er.launch_angles[k], er1.launch_angles[k]) and np.array_equal(er.zs[k], er1.zs[k])
+        assert np.array_equal(er.ts[k], er1.ts[k]) and er.failed_eray_theta_brackets[k] == er1.failed_eray_theta_brackets[k]
+    want = np.histogram(ref.ts[:, -1], bins=64, range=(66.0, 68.0))[0]
+    assert np.array_equal(h, want) and h.sum() > 0 and len(edges) == 65
+
+
+def test_device_resident_fan_equals_the_eager_fan(lib):
+    """pgr_fan_* (a fan whose results stay in HBM) and the RayFan on top of it: the same numbers as the host-pointer
+    entry -- per-ray arrays, trajectories with and without the compaction of dropped rays, each array fetched on its
+    own -- and pr.shoot_rays(device_resident=True) equals device_resident=False attribute by attribute, dropped rays
+    gone, the trajectories crossing PCIe only when read."""
+    import pygenray_amd as pr
+    arrs = munk_arrays(100e3, z=np.arange(0, 4000, 1.0), bathy=5000.0)     # table ends above the sea floor: deep rays leave it
+    theta = np.linspace(-20, 20, 300)
+    y0 = y0_for(oracle, arrs, 1000.0, 0.0, -theta)
+    env = lib.EnvHandle(*arrs)
+    ref = env.shoot_fan(y0, 0.0, 100e3, 41, sample_major=True, stored_sign=True)
+    drop = ref["status"] != 0
+    assert 10 < drop.sum() < 200
+    h = lib.FanHandle(env, 0.0, 100e3, 41, y0=y0, stored_sign=True)
+    n, m = h.wait()
+    assert (n, m) == (300, int((~drop).sum()))
+    rays = h.fetch_rays()
+    for k in ("end", "n_bott", "n_surf", "status", "n_steps", "n_rej"):
+        assert np.array_equal(rays[k], ref[k], equal_nan=True), k
+    full = h.fetch_samples(compact=False)
+    for k in "Tzp":
+        assert full[k].shape == (41, 300) and np.array_equal(full[k], ref[k], equal_nan=True), k
+    only_z = h.fetch_samples(("z",))
+    assert list(only_z) == ["z"] and np.array_equal(only_z["z"], ref["z"][:, ~drop])
+    h.close()
+    # end states only, initial states computed on the device from the angles (correctly rounded sine)
+    c0 = oracle.bilinear(0.0, 1000.0, arrs[2], arrs[3], arrs[0])
+    h2 = lib.FanHandle(env, 0.0, 100e3, 0, ode_angles_deg=-theta, source_depth=1000.0, c_source=c0)
+    r2 = h2.fetch_rays()
+    p0 = oracle.math_fn("sin", np.radians(-theta)) / c0
+    ref2 = env.shoot_fan(np.stack([np.zeros(300), np.full(300, 1000.0), p0], 1), 0.0, 100e3, 1, save=False)
+    assert np.array_equal(r2["end"], ref2["end"], equal_nan=True) and np.array_equal(r2["status"], ref2["status"])
+    with pytest.raises(lib.PgrError):
+        h2.fetch_samples()
+    h2.close()
+    env.close()
+    # the drop-in API, both ways
+    z = np.arange(0, 4000, 1.0); r = np.linspace(0, 100e3, 100)
+    eo = pr.OceanEnvironment2D(pr.DataArray(np.tile(pr.munk_ssp(z), (100, 1)), dims=["range", "depth"], coords={"range": r, "depth": z}),
+                               pr.DataArray(np.full(100, 5000.0), dims=["range"], coords={"range": r}), flat_earth_transform=False)
+    a = pr.shoot_rays(1000.0, 0.0, theta, 100e3, 41, eo, debug=False, flatearth=False, device_resident=False)
+    b = pr.shoot_rays(1000.0, 0.0, theta, 100e3, 41, eo, debug=False, flatearth=False, device_resident=True)
+    assert not a.device_resident and b.device_resident and len(a) == len(b) == m
+    assert np.array_equal(b.zs_end, a.zs[:, -1]) and np.array_equal(b.ts_end, a.ts[:, -1]) and b.device_resident
+    for k in ("thetas", "n_botts", "n_surfs", "source_depths", "rs", "zs", "ts", "ps", "ray_ids"):
+        assert np.array_equal(getattr(a, k), getattr(b, k)), k
+    assert not b.device_resident and b[3:7].zs.shape == (4, 41) and len(a + b) == 2 * m
+    # backwards shot, device resident
+    c_ = pr.shoot_rays(1000.0, 100e3, theta, 0.0, 41, eo, debug=False, flatearth=False, device_resident=True)
+    d_ = pr.shoot_rays(1000.0, 100e3, theta, 0.0, 41, eo, debug=False, flatearth=False, device_resident=False)
+    assert np.array_equal(c_.rs, d_.rs) and np.array_equal(c_.zs, d_.zs) and np.array_equal(c_.thetas, d_.thetas)
+
+
+def test_many_fans_in_flight_on_user_streams_keep_their_wave_maps(lib):
+    """VERDICT r02 'robustness': 12 fans in flight at once on 12 user streams through pgr_shoot_fan_device on ONE
+    environment, each big enough for the cost-aware wave placement (a per-launch map in device memory): every fan's
+    result equals the one-at-a-time result -- no launch's map is handed to another while its kernel may read it."""
+    import torch
+    from pygenray_amd.device_fan import DeviceFan, fan_y0
+    arrs = munk_arrays(200e3)
+    env = lib.EnvHandle(*arrs)
+    fans, streams = [], []
+    for k in range(12):
+        n = 90_000 + 1000 * k       # 1407 .. 1579 waves: single-round placement, a different map each
+        y0 = fan_y0(arrs, 1000.0, 0.0, -np.linspace(-20 + 0.1 * k, 20, n))
+        fans.append(DeviceFan(env, y0, 0.0, 200e3, 1, save=False))
+        streams.append(torch.cuda.Stream())
+    ref = []
+    for f in fans:
+        f.run()
+        torch.cuda.synchronize()
+        ref.append((f.end.clone(), f.n_steps.clone(), f.status.clone()))
+        f.end.zero_(); f.n_steps.zero_()
+    torch.cuda.synchronize()
+    for rep in range(2):
+        for f, st in zip(fans, streams):
+            with torch.cuda.stream(st):
+                f.run()
+        torch.cuda.synchronize()
+        for f, (e, ns_, s_) in zip(fans, ref):
+            assert torch.equal(torch.nan_to_num(f.end), torch.nan_to_num(e)) and torch.equal(f.n_steps, ns_) and torch.equal(f.status, s_)
+    env.close()
+
+
 def test_arrival_time_histogram_equals_numpy(lib):
     """pgr_arrival_histogram_device (BASELINE configs[4]) against np.histogram, count for count:
     values on bin edges and on the range ends, NaN, dropped rays, strided views, packed end records."""

@@ -279,6 +279,121 @@ def test_sharded_fan_all_gather_gloo_world2(tmp_path):
         assert p.returncode == 0 and "RANK_OK" in o, e[-2000:]
 
 
+
+# ---------------------------------------------------------------- the sharded API on gloo (world_size 2)
+_SHARD_COMMON = r"""
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np, torch, torch.distributed as dist
+import oracle
+import pygenray_amd as pr
+from helpers import munk
+from pygenray_amd.distributed import (shoot_rays_sharded, find_eigenrays_sharded, arrival_histogram_sharded,
+                                      pack_end_records)
+# a steep seamount at 30 km: the rays that hit its face bounce backwards and are DROPPED (status 3) in the middle of
+# the fan, so brackets form across the gap (REF/eigenrays.py:65-79 works on the surviving rays, Q12)
+z = np.arange(0, 6000, 5.0); r = np.linspace(0, 60e3, 13); br = np.linspace(0, 60e3, 61)
+ssp = pr.DataArray(np.tile(munk(z), (len(r), 1)), dims=["range", "depth"], coords={"range": r, "depth": z})
+bathy = pr.DataArray(5000 - 2600 * np.exp(-((br - 30e3) / 2.5e3) ** 2), dims=["range"], coords={"range": br})
+env = pr.OceanEnvironment2D(ssp, bathy, flat_earth_transform=False)
+arrs = pr._unpack_envi(env, flatearth=False)
+ZS, X1, S = 1000.0, 60e3, 21
+theta = np.linspace(-19, 19, 77)
+
+def compute(y0_local, x0, x1, backwards, n_pad):     # the oracle stands in for the HIP fan on this CPU-only box
+    o = oracle.shoot_fan(*arrs, y0_local, x0, x1, 2)
+    end = np.stack([o["T"][:, -1], o["z"][:, -1], o["p"][:, -1]], 1)
+    return pack_end_records(torch.from_numpy(end), torch.from_numpy(o["n_bott"]), torch.from_numpy(o["n_surf"]),
+                            torch.from_numpy(o["status"]), n_pad)
+
+C0 = oracle.bilinear(0.0, ZS, arrs[2], arrs[3], arrs[0])
+def shoot1(th_user, S_):
+    y0 = np.array([[0.0, ZS, np.sin(np.radians(-th_user)) / C0]])
+    return oracle.shoot_fan(*arrs, y0, 0.0, X1, S_)
+
+def refine(z1s, z2s, th1s, th2s, rd):                # REF/eigenrays.py:206-268, bracket by bracket
+    n = len(z1s)
+    found = np.zeros(n, bool); th = np.zeros(n)
+    T = np.zeros((n, S)); Z = np.zeros((n, S)); P = np.zeros((n, S)); nb = np.zeros(n, np.int64); ns = np.zeros(n, np.int64)
+    for k in range(n):
+        z1, z2, t1, t2 = z1s[k], z2s[k], th1s[k], th2s[k]
+        t = t1 - (z1 + rd) * (t2 - t1) / (z2 - z1)
+        for it in range(23):
+            o = shoot1(t, S)
+            if o["status"][0] != 0:
+                break
+            zr = -o["z"][0, -1]
+            if abs(zr + rd) < 1.0:
+                found[k] = True; th[k] = t
+                T[k], Z[k], P[k], nb[k], ns[k] = o["T"][0], -o["z"][0], -o["p"][0], o["n_bott"][0], o["n_surf"][0]
+                break
+            if np.sign(zr + rd) == np.sign(z1 + rd): z1, t1 = zr, t
+            else: z2, t2 = zr, t
+            t = t1 - (z1 + rd) * (t2 - t1) / (z2 - z1)
+            if it > 20: break
+    return found, th, np.linspace(0.0, X1, S), T, Z, P, nb, ns
+
+def run(tag):
+    fan, raw = shoot_rays_sharded(ZS, 0.0, theta, X1, env, flatearth=False, compute=compute, return_all=True)
+    er = find_eigenrays_sharded(fan, [1000.0, 2500.0], ZS, 0.0, X1, S, env, refine=refine)
+    h, edges = arrival_histogram_sharded(ZS, 0.0, theta, X1, env, 32, 39.0, 41.0, flatearth=False, compute=compute)
+    out = dict(status=raw["status"], thetas=fan.thetas, ts=fan.ts, zs=fan.zs, ps=fan.ps, nb=fan.n_botts, hist=h, edges=edges)
+    for k in (0, 1):
+        out[f"e{k}_th"] = er.launch_angles[k]; out[f"e{k}_ts"] = er.ts[k]; out[f"e{k}_zs"] = er.zs[k]
+        out[f"e{k}_nb"] = er.n_botts[k]; out[f"e{k}_ra"] = er.received_angles[k]
+        out[f"e{k}_failed"] = np.array(er.failed_eray_theta_brackets[k], dtype=float).reshape(-1, 2)
+        out[f"e{k}_n"] = np.array([er.num_eigenrays[[1000.0, 2500.0][k]], er.num_eigenrays_found[k]])
+    np.savez(tag, **out)
+"""
+
+_SHARD_WORKER = _SHARD_COMMON + r"""
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=int(sys.argv[1]), world_size=2)
+run(sys.argv[2])
+dist.barrier(); dist.destroy_process_group()
+print("RANK_OK")
+"""
+
+_SHARD_SINGLE = _SHARD_COMMON + r"""
+run(sys.argv[1])
+print("SINGLE_OK")
+"""
+
+
+def test_sharded_shoot_eigenrays_histogram_gloo_world2_equals_single_process(tmp_path):
+    """pygenray_amd.distributed's API (shoot_rays_sharded -> find_eigenrays_sharded, arrival_histogram_sharded) on two
+    gloo ranks against the very same calls in one process without torch.distributed: every rank must hold the
+    single-process fan (launch order, dropped rays gone), the same EigenRays -- brackets straddle the two ranks' rays
+    (with a strided deal EVERY bracket does) and one spans the rays a seamount drops in the middle of the fan --
+    and the same histogram.  The oracle stands in for the HIP fan and for the device refinement (CPU-only box)."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    w = tmp_path / "worker.py"; w.write_text(_SHARD_WORKER % dict(root=ROOT, port=port))
+    one = tmp_path / "single.py"; one.write_text(_SHARD_SINGLE % dict(root=ROOT))
+    procs = [subprocess.Popen([sys.executable, str(w), str(r), str(tmp_path / f"rank{r}.npz")], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(2)]
+    p1 = subprocess.run([sys.executable, str(one), str(tmp_path / "single.npz")], capture_output=True, text=True, timeout=600)
+    assert p1.returncode == 0 and "SINGLE_OK" in p1.stdout, p1.stderr[-2000:]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0 and "RANK_OK" in o, e[-2000:]
+    ref = np.load(tmp_path / "single.npz")
+    # the scenario is the one the docstring promises
+    st = ref["status"]
+    inner = np.where(st != 0)[0]
+    assert len(inner) >= 3 and inner.min() > 0 and inner.max() < len(st) - 1          # dropped rays INSIDE the fan
+    assert ref["e0_n"][0] >= 4 and ref["e0_n"][1] >= 3 and ref["e1_n"][0] >= 2
+    th = ref["thetas"]
+    gap = np.where(np.diff(th) > 1.5 * (38 / 76))[0]                                   # the fan's neighbours across the gap
+    assert len(gap) >= 1
+    spans = [rd for rd in (1000.0, 2500.0) if np.intersect1d(np.where(np.diff(np.sign(ref["zs"][:, -1] + rd)))[0], gap).size]
+    assert spans, "no bracket spans the dropped rays"
+    assert ref["hist"].sum() > 0.5 * (st == 0).sum()
+    for r in range(2):
+        got = np.load(tmp_path / f"rank{r}.npz")
+        assert sorted(got.files) == sorted(ref.files)
+        for k in ref.files:
+            assert np.array_equal(got[k], ref[k], equal_nan=True), (r, k)
+
 def test_pack_and_interleave_single_process():
     import torch
     from pygenray_amd.distributed import pack_end_records, all_gather_fan, shard_indices
