@@ -77,6 +77,10 @@ extern "C" {
                                       slots -- the end record the multi-GPU all-gather ships, written by
                                       the kernel instead of packed afterwards */
 
+#define PGR_LAUNCH_SLOWNESS 1024u   /* (pgr_fan_launch without y0) the array of launch angles holds the initial vertical
+                                      slowness p0[k] = sin(radians(angle_k)) / c_source itself, computed by the caller
+                                      (REF/launch_rays.py:144): y0[k] = [0, source_depth, p0[k]] is assembled on the device */
+
 #define PGR_SKIP_NAN_Y0 512u       /* rays whose y0[k][2] is NaN are not integrated (status PGR_RAY_SKIPPED): the
                                       eigenray refinement parks its finished brackets this way */
 
@@ -157,6 +161,11 @@ int pgr_fan_wait(pgr_fan* fan, int64_t* n_rays, int64_t* n_ok);
 int pgr_fan_fetch_rays(pgr_fan* fan, double* end_state, int32_t* n_bott, int32_t* n_surf, int32_t* status,
                        int32_t* n_steps, int32_t* n_rej);
 int pgr_fan_fetch_samples(pgr_fan* fan, double* T, double* z, double* p, uint32_t flags);
+/* The per-ray results of the M surviving rays only, in launch order (what a pygenray RayFan keeps): end_state [M][3],
+ * n_bott / n_surf [M] as int64; per_ray_in [N] -> per_ray_out [M] squeezes any per-ray HOST array of the caller's
+ * (the stored launch angles) the same way.  Any pair may be NULL.  M from pgr_fan_wait. */
+int pgr_fan_fetch_rays_compact(pgr_fan* fan, const double* per_ray_in, double* per_ray_out, double* end_state,
+                               int64_t* n_bott, int64_t* n_surf);
 void pgr_fan_destroy(pgr_fan* fan);
 
 /* Eigenray refinement: pygenray's _find_single_eigenray (REF/eigenrays.py:206-268) for nbk brackets at

@@ -38,6 +38,7 @@ PGR_COMPACT = 128
 PGR_PACKED_END = 256
 PGR_SAVE_LINSPACE = 8
 PGR_SKIP_NAN_Y0 = 512
+PGR_LAUNCH_SLOWNESS = 1024
 
 RAY_STATUS = {0: "ok", 1: "vertical", 2: "bbox", 3: "backward", 4: "step_too_small",
               5: "max_steps", 6: "bottom_angle_range", 7: "event_error", 8: "skipped"}
@@ -372,7 +373,7 @@ class FanHandle:
 
     def __init__(self, env, x0, x1, S, y0=None, ode_angles_deg=None, source_depth=0.0, c_source=1.0, rtol=1e-9,
                  atol=1e-6, terminate_backwards=True, max_steps=1_000_000, stored_sign=False, exact_samples=False,
-                 exact_bisection=False):
+                 exact_bisection=False, p0=None):
         L = load()
         L.pgr_fan_launch.restype = ctypes.c_int
         L.pgr_fan_launch.argtypes = [_vp, _vp, _vp, ctypes.c_double, ctypes.c_double, _i64, ctypes.c_double, ctypes.c_double,
@@ -389,12 +390,16 @@ class FanHandle:
         if y0 is not None:
             y0 = _c(y0).reshape(-1, 3)
             n = len(y0)
+        elif p0 is not None:      # the caller's own sin(radians(angle)) / c per ray (PGR_LAUNCH_SLOWNESS)
+            ode_angles_deg = _c(p0).reshape(-1)
+            n = len(ode_angles_deg)
         else:
             ode_angles_deg = _c(ode_angles_deg).reshape(-1)
             n = len(ode_angles_deg)
         self.N, self.S = n, int(S)
         flags = (PGR_TERMINATE_BACKWARDS if terminate_backwards else 0) | (PGR_STORED_SIGN if stored_sign else 0) | \
-            (PGR_EXACT_SAMPLES if exact_samples else 0) | (PGR_EXACT_BISECTION if exact_bisection else 0)
+            (PGR_EXACT_SAMPLES if exact_samples else 0) | (PGR_EXACT_BISECTION if exact_bisection else 0) | \
+            (PGR_LAUNCH_SLOWNESS if p0 is not None else 0)
         h = _vp()
         check(L.pgr_fan_launch(env._h, _vptr(y0), _vptr(ode_angles_deg), float(source_depth), float(c_source), n,
                                float(x0), float(x1), self.S, float(rtol), float(atol), flags, int(max_steps),
@@ -416,6 +421,28 @@ class FanHandle:
         check(load().pgr_fan_fetch_rays(self._h, _vptr(end), _vptr(nb), _vptr(ns), _vptr(st), _vptr(n1), _vptr(n2)))
         self.M = int(np.count_nonzero(st == 0))
         return dict(end=end, n_bott=nb, n_surf=ns, status=st, n_steps=n1, n_rej=n2)
+
+    def fetch_rays_compact(self, per_ray=None):
+        """The surviving rays only (launch order): end [M, 3], n_bott / n_surf [M] int64 and, squeezed the same way,
+        the caller's per-ray array `per_ray` [N] -> [M]."""
+        L = load()
+        L.pgr_fan_fetch_rays_compact.restype = ctypes.c_int
+        L.pgr_fan_fetch_rays_compact.argtypes = [_vp] * 6
+        if self.M is None:
+            self.wait()
+        m = self.M
+        end = np.empty((m, 3)); nb = np.empty(m, np.int64); ns = np.empty(m, np.int64)
+        src = None if per_ray is None else _c(per_ray).reshape(-1)
+        out = None if per_ray is None else np.empty(m)
+        check(L.pgr_fan_fetch_rays_compact(self._h, _vptr(src), _vptr(out), _vptr(end), _vptr(nb), _vptr(ns)))
+        return dict(end=end, n_bott=nb, n_surf=ns, per_ray=out)
+
+    def status(self):
+        """status [N] (waits for the kernel)."""
+        st = np.empty(self.N, np.int32)
+        check(load().pgr_fan_fetch_rays(self._h, None, None, None, _vptr(st), None, None))
+        self.M = int(np.count_nonzero(st == 0))
+        return st
 
     def fetch_samples(self, which=("T", "z", "p"), compact=True):
         """-> dict name -> (S, M) array (M = surviving rays when `compact`, else all N; dropped rays are NaN then)."""

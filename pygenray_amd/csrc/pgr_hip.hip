@@ -253,6 +253,8 @@ struct pgr_env {
     // more than the kernel's launch; hipFree also waits for the whole device): at most 4 buffers / 64 GB
     std::vector<std::pair<void*, size_t>> fan_pool;
     std::mutex fan_pool_mutex;
+    void* stage = nullptr;   // page-locked host staging of the compacted per-ray fetch (grow-only)
+    size_t stage_bytes = 0;
     void* ws2 = nullptr;   // second grow-only workspace: the compacted trajectories of PGR_COMPACT
     size_t ws2_bytes = 0;
     std::mutex ws_mutex;
@@ -529,6 +531,7 @@ extern "C" void pgr_env_destroy(pgr_env* env)
     }
     if (env->ws) (void)hipFree(env->ws);
     if (env->ws2) (void)hipFree(env->ws2);
+    if (env->stage) (void)hipHostFree(env->stage);
     for (auto& pb : env->fan_pool) (void)hipFree(pb.first);
     if (env->stream) (void)hipStreamDestroy(env->stream);
     delete env;
@@ -1251,6 +1254,15 @@ __global__ void pgr_y0_kernel(const double* __restrict__ ang_deg, int64_t N, dou
     y0[3 * k + 2] = pgr_cr_sin(ang_deg[k] * (M_PI / 180.0)) / c_source;
 }
 
+__global__ void pgr_y0_from_p0_kernel(const double* __restrict__ p0, int64_t N, double source_depth, double* __restrict__ y0)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    y0[3 * k + 0] = 0.0;
+    y0[3 * k + 1] = source_depth;
+    y0[3 * k + 2] = p0[k];
+}
+
 extern "C" int pgr_initial_states_device(int device, const double* ode_angles_deg, int64_t N, double source_depth,
                                          double c_source, double* y0, void* stream)
 {
@@ -1319,7 +1331,7 @@ extern "C" int pgr_fan_launch(pgr_env* env, const double* y0, const double* ode_
     }
     pgr_fan* f = new pgr_fan();
     f->env = env; f->N = N; f->S = S; f->save = (S > 0);
-    f->flags = (flags & ~(uint32_t)(PGR_COMPACT | PGR_PACKED_END)) | PGR_SAMPLE_MAJOR | PGR_SAVE_LINSPACE;
+    f->flags = (flags & ~(uint32_t)(PGR_COMPACT | PGR_PACKED_END | PGR_LAUNCH_SLOWNESS)) | PGR_SAMPLE_MAJOR | PGR_SAVE_LINSPACE;
     f->stream = env->stream;
     const size_t ns_bytes = (size_t)N * (size_t)S * sizeof(double);
     const size_t sizes[11] = {(size_t)N * 24, (size_t)(S > 0 ? S : 1) * 8, ns_bytes, ns_bytes, ns_bytes, (size_t)N * 24,
@@ -1355,8 +1367,16 @@ extern "C" int pgr_fan_launch(pgr_env* env, const double* y0, const double* ode_
         } else {
             // the angles ride in the (not yet used) end_state array; y0 is computed on the device
             if (hipMemcpyAsync(f->end, ode_angles_deg, (size_t)N * 8, hipMemcpyHostToDevice, st) != hipSuccess) { rc = fail("pgr_fan_launch: upload of the angles"); break; }
-            rc = pgr_initial_states_device(env->device, f->end, N, source_depth, c_source, f->y0, (void*)st);
-            if (rc) break;
+            if (flags & PGR_LAUNCH_SLOWNESS) {
+                // ... or assembled from the caller's own p0[k] = sin(radians(angle)) / c (REF/launch_rays.py:144): a third
+                // of the bytes of y0 cross PCIe and nobody builds an [N][3] array on the host
+                hipLaunchKernelGGL(pgr_y0_from_p0_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, (const double*)f->end, N,
+                                   source_depth, f->y0);
+                if (hipGetLastError() != hipSuccess) { rc = fail("pgr_fan_launch: y0 kernel"); break; }
+            } else {
+                rc = pgr_initial_states_device(env->device, f->end, N, source_depth, c_source, f->y0, (void*)st);
+                if (rc) break;
+            }
         }
         if (hipEventCreateWithFlags(&up, hipEventDisableTiming) != hipSuccess || hipEventRecord(up, st) != hipSuccess) { rc = fail("pgr_fan_launch: event"); break; }
         rc = pgr_shoot_fan_device(env, f->y0, N, source_range, receiver_range, f->r, S > 0 ? S : 1, rtol, atol, f->flags, max_steps,
@@ -1417,6 +1437,61 @@ extern "C" int pgr_fan_fetch_rays(pgr_fan* f, double* end_state, int32_t* n_bott
     if (n_steps) HIPCHK(hipMemcpy(n_steps, f->n1, n * 4, hipMemcpyDeviceToHost));
     if (n_rej) HIPCHK(hipMemcpy(n_rej, f->n2, n * 4, hipMemcpyDeviceToHost));
     PGR_MARK(t0, "pgr_fan_fetch_rays: done");
+    return 0;
+}
+
+// The per-ray results of the SURVIVING rays only, in launch order, as pygenray's RayFan holds them (dropped rays
+// vanish, REF/launch_rays.py:166-171; bounce counts as int64): the device arrays come over in one piece into a
+// page-locked staging buffer of the environment (grow-only) and a few threads squeeze them into the caller's arrays.
+extern "C" int pgr_fan_fetch_rays_compact(pgr_fan* f, const double* per_ray_in, double* per_ray_out, double* end_state,
+                                          int64_t* n_bott, int64_t* n_surf)
+{
+    if (!f) return fail("pgr_fan_fetch_rays_compact: null fan");
+    std::lock_guard<std::mutex> lock(f->m);
+    int rc = fan_finish(f);
+    if (rc) return rc;
+    pgr_env* env = f->env;
+    const size_t n = (size_t)f->N, M = (size_t)f->M;
+    const size_t need = n * 32;     // end[N][3] doubles, n_bott[N], n_surf[N] int32
+    std::lock_guard<std::mutex> wlock(env->ws_mutex);
+    if (need > env->stage_bytes) {
+        if (env->stage) (void)hipHostFree(env->stage);
+        env->stage = nullptr; env->stage_bytes = 0;
+        if (hipHostMalloc(&env->stage, need, hipHostMallocDefault) != hipSuccess) { env->stage = nullptr; return fail("pgr_fan_fetch_rays_compact: host allocation failed"); }
+        env->stage_bytes = need;
+    }
+    char* sb = (char*)env->stage;
+    const double* h_end = (const double*)sb;
+    const int32_t* h_nb = (const int32_t*)(sb + n * 24);
+    const int32_t* h_ns = (const int32_t*)(sb + n * 28);
+    hipStream_t st = f->stream;
+    if (end_state) HIPCHK(hipMemcpyAsync((void*)h_end, f->end, n * 24, hipMemcpyDeviceToHost, st));
+    if (n_bott) HIPCHK(hipMemcpyAsync((void*)h_nb, f->nb, n * 4, hipMemcpyDeviceToHost, st));
+    if (n_surf) HIPCHK(hipMemcpyAsync((void*)h_ns, f->ns, n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt < 1 ? 1 : (nt > 8 ? 8 : nt);
+    if (M < 200000) nt = 1;
+    const int* keep = f->keep.data();
+    auto work = [&](size_t m0, size_t m1) {
+        for (size_t m = m0; m < m1; m++) {
+            const size_t k = (size_t)keep[m];
+            if (per_ray_in && per_ray_out) per_ray_out[m] = per_ray_in[k];
+            if (end_state) { end_state[3 * m] = h_end[3 * k]; end_state[3 * m + 1] = h_end[3 * k + 1]; end_state[3 * m + 2] = h_end[3 * k + 2]; }
+            if (n_bott) n_bott[m] = h_nb[k];
+            if (n_surf) n_surf[m] = h_ns[k];
+        }
+    };
+    if (nt == 1) work(0, M);
+    else {
+        std::vector<std::thread> th;
+        const size_t per = (M + nt - 1) / nt;
+        for (unsigned t = 0; t < nt; t++) {
+            const size_t m0 = (size_t)t * per, m1 = m0 + per < M ? m0 + per : M;
+            if (m0 < m1) th.emplace_back(work, m0, m1);
+        }
+        for (auto& t : th) t.join();
+    }
     return 0;
 }
 

@@ -113,10 +113,8 @@ def _launch_device_fan(source_depth, source_range, ode_angles_deg, receiver_rang
     if device_y0:
         h = _lib.FanHandle(env, x0, x1, num_range_save, ode_angles_deg=ang, source_depth=source_depth, c_source=c, **kw)
     else:
-        y0 = np.zeros((len(ang), 3))
-        y0[:, 1] = source_depth
-        y0[:, 2] = _initial_slowness(ang, c)
-        h = _lib.FanHandle(env, x0, x1, num_range_save, y0=y0, **kw)
+        # NumPy's own sin(radians(.)) / c, as the reference computes it; [0, z_s, p0] is assembled on the device
+        h = _lib.FanHandle(env, x0, x1, num_range_save, p0=_initial_slowness(ang, c), source_depth=source_depth, **kw)
     r = np.linspace(x0, x1, int(num_range_save))
     return h, (-r if backwards else r)
 
@@ -143,25 +141,24 @@ def shoot_rays(source_depth, source_range, launch_angles, receiver_range, num_ra
     None (default) -- device resident from 2 million samples per array on (a 1e5 x 1001 fan: 7 ms instead of 50)."""
     if type(launch_angles) is list:
         launch_angles = np.array(launch_angles)
-    launch_angles = -np.asarray(launch_angles, dtype=float)
-    n = len(launch_angles)
+    user = np.asarray(launch_angles, dtype=float)
+    n = len(user)
     if n < 70:
-        ode = -launch_angles     # shoot_ray flips the (already flipped) angle again
-        stored = ode             # shoot_ray stores its flipped angle (REF/launch_rays.py:251,318)
+        ode = stored = user      # shoot_ray flips the (already flipped) angle again and stores it (REF/launch_rays.py:251,318)
     else:
-        ode = launch_angles
-        stored = -launch_angles  # REF/launch_rays.py:180
+        ode = -user              # REF/launch_rays.py:67
+        stored = user            # REF/launch_rays.py:180
     if device_resident is None:
         device_resident = n * int(num_range_save) >= 2_000_000
     if device_resident and n > 0:
         h, r = _launch_device_fan(source_depth, source_range, ode, receiver_range, num_range_save, environment, rtol,
                                   terminate_backwards, flatearth, device=device, stored_sign=True)
-        rays = h.fetch_rays()                       # waits for the kernel; the small per-ray arrays only
-        _report_drops(rays["status"], debug)
-        keep = rays["status"] == 0
-        M = int(keep.sum())
-        return RayFan.from_device(h, stored[keep], r, rays["end"][keep], rays["n_bott"][keep].astype(np.int64),
-                                  rays["n_surf"][keep].astype(np.int64), np.full(M, source_depth))
+        if debug:
+            _report_drops(h.status(), debug)
+        h.wait()                                    # the kernel; then only the surviving rays' per-ray arrays cross PCIe
+        rays = h.fetch_rays_compact(per_ray=stored)
+        return RayFan.from_device(h, rays["per_ray"], r, rays["end"], rays["n_bott"], rays["n_surf"],
+                                  np.full(h.M, source_depth))
     # stored convention z -> -z, p -> -p (REF/ray_objects.py:51-52) applied by the kernel's stores
     out = _shoot_ode_angles(source_depth, source_range, ode, receiver_range, num_range_save,
                             environment, rtol, terminate_backwards, flatearth, device=device,

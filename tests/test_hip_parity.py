@@ -841,6 +841,12 @@ def test_device_resident_fan_equals_the_eager_fan(lib):
     full = h.fetch_samples(compact=False)
     for k in "Tzp":
         assert full[k].shape == (41, 300) and np.array_equal(full[k], ref[k], equal_nan=True), k
+    rc_ = h.fetch_rays_compact(per_ray=theta)
+    assert np.array_equal(rc_["end"], ref["end"][~drop]) and np.array_equal(rc_["per_ray"], theta[~drop])
+    assert rc_["n_bott"].dtype == np.int64 and np.array_equal(rc_["n_bott"], ref["n_bott"][~drop]) and np.array_equal(rc_["n_surf"], ref["n_surf"][~drop])
+    hp = lib.FanHandle(env, 0.0, 100e3, 0, p0=y0[:, 2], source_depth=1000.0)         # [0, z_s, p0] assembled on the device
+    assert np.array_equal(hp.fetch_rays()["end"], ref["end"], equal_nan=True)
+    hp.close()
     only_z = h.fetch_samples(("z",))
     assert list(only_z) == ["z"] and np.array_equal(only_z["z"], ref["z"][:, ~drop])
     h.close()
