@@ -7,7 +7,7 @@ C ABI of ``include/pgr.h``.  There is no CPU fallback: importing works anywhere,
 needs ``libpgr_hip.so`` and a GPU.
 """
 from .xr_lite import DataArray
-from .environment import OceanEnvironment2D, munk_ssp, eflat, eflatinv
+from .environment import OceanEnvironment2D, munk_ssp, eflat, eflatinv, flat_earth_c
 from .ray_objects import Ray, RayFan, EigenRays
 from .launch_rays import shoot_rays, shoot_ray, _unpack_envi
 from .eigenrays import find_eigenrays
@@ -15,7 +15,7 @@ from .host_physics import (derivsrd, bottom_bounce, surface_bounce, ray_bounding
                            ray_angle, bilinear_interp, linear_interp, vertical_ray)
 from . import _lib
 
-__all__ = ["OceanEnvironment2D", "munk_ssp", "eflat", "eflatinv", "DataArray", "Ray", "RayFan",
+__all__ = ["OceanEnvironment2D", "munk_ssp", "eflat", "eflatinv", "flat_earth_c", "DataArray", "Ray", "RayFan",
            "EigenRays", "shoot_rays", "shoot_ray", "find_eigenrays", "derivsrd", "bottom_bounce",
            "surface_bounce", "ray_bounding_box_event", "ray_angle", "bilinear_interp",
            "linear_interp", "vertical_ray"]

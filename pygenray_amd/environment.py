@@ -62,6 +62,39 @@ def eflatinv(depf, lat, csf=None):
     return dep, cs
 
 
+def flat_earth_c(c, verbose=False, n_cpus=None, chunk_size=None):
+    """Flat-earth transformed sound-speed slice, latitude varying along the range (REF/environment.py:239-303): for
+    every range column ``eflat(depth, lat_i, c[:, i])`` gives transformed depths and speeds, and the speeds are
+    interpolated back -- linearly, NaN outside the transformed span, as ``xarray.DataArray.interp`` does -- onto the
+    ORIGINAL depth grid.  `c`: dims ('depth', 'range') or ('range', 'depth') with coordinates depth, range and
+    ``lat`` (one latitude per range).  ``n_cpus`` / ``chunk_size`` (the reference's process pool) are accepted and
+    ignored: the columns are a few NumPy calls each.  Returns a DataArray laid out like the reference's result
+    (dims ('range', 'depth'), coordinates range, depth, lat)."""
+    _as_dataarray(c, "c")
+    if c.ndim != 2 or "depth" not in c.dims or "range" not in c.dims:
+        raise ValueError("c must be 2D with dimensions 'depth' and 'range'.")
+    coords = c.coords
+    if "lat" not in coords:
+        raise ValueError("c must have a 'lat' coordinate along 'range'.")
+    v = np.asarray(c.values, dtype=float)
+    if tuple(c.dims) == ("depth", "range"):
+        v = v.T
+    z = coord_values(c, "depth")
+    r = coord_values(c, "range")
+    lat = np.asarray(getattr(coords["lat"], "values", coords["lat"]), dtype=float).reshape(-1)
+    if len(lat) != len(r):
+        raise ValueError("the 'lat' coordinate must have one entry per range.")
+    out = np.empty_like(v)
+    for i in range(len(r)):
+        depf, cf = eflat(z, lat[i], v[i])
+        col = np.interp(z, depf, cf)
+        col[(z < depf[0]) | (z > depf[-1])] = np.nan      # xarray's interp: NaN outside the source coordinates
+        out[i] = col
+    if verbose:
+        print(f"Processed {len(r)} range points")
+    return DataArray(out, dims=["range", "depth"], coords={"range": r, "depth": z, "lat": lat})
+
+
 def _as_dataarray(obj, what):
     if not is_dataarray(obj):
         raise TypeError(f"{what} must be an xarray DataArray.")
@@ -138,6 +171,16 @@ class OceanEnvironment2D:
                                        coords={"range": coord_values(self.bathymetry, "range")})
         self._cache = {}
 
+    def flat_earth_transform_rd(self):
+        """Earth flattening computed for each range / latitude independently (REF/environment.py:156-173):
+        ``sound_speed`` must carry a ``lat`` coordinate along ``range``; the bathymetry is left as it is (as in
+        the reference)."""
+        c_fe = flat_earth_c(self.sound_speed, verbose=False)
+        self.sound_speed_fe = c_fe
+        self.dcdz = c_fe.differentiate("depth")
+        self.bathymetry_fe = self.bathymetry.copy(deep=True)
+        self._cache = {}
+
     def plot(self, **kwargs):
         """2D slice of the environment (REF/environment.py:171-215)."""
         from matplotlib import pyplot as plt
@@ -201,4 +244,4 @@ def _check_monotone(rin, zin, depth_ranges):
         raise Exception("Bathymetry range coordinates must be monotonically increasing.")
 
 
-__all__ = ["OceanEnvironment2D", "munk_ssp", "eflat", "eflatinv", "DataArray"]
+__all__ = ["OceanEnvironment2D", "munk_ssp", "eflat", "eflatinv", "flat_earth_c", "DataArray"]

@@ -290,18 +290,62 @@ class EigenRays:
             self.ray_id_int[ridx] = np.array(ids_int)
 
     def plot_angle_time(self, ridxs=None, **kwargs):
+        """Received angle against arrival time (REF/ray_objects.py:550-561)."""
         from matplotlib import pyplot as plt
         for ridx in (ridxs if ridxs is not None else list(self.received_angles.keys())):
             plt.scatter(self.ts[ridx][:, -1], self.received_angles[ridx], **kwargs)
         plt.xlabel("time [s]")
-        plt.ylabel("received angle [°]")
+        plt.ylabel("received angle [deg]")
+        plt.title("Received Angle vs Time")
 
     def plot(self, ridxs=[0], **kwargs):
+        """All eigenrays of the given receiver-depth indices (REF/ray_objects.py:563-585)."""
         from matplotlib import pyplot as plt
+        if isinstance(ridxs, (int, np.integer)):
+            ridxs = [ridxs]
+        kw = {"c": "k"}
+        kw.update(kwargs)
         for ridx in ridxs:
-            plt.plot(self.rs[ridx].T, self.zs[ridx].T, **kwargs)
+            plt.plot(self.rs[ridx].T, self.zs[ridx].T, **kw)
         plt.xlabel("range [m]")
         plt.ylabel("depth [m]")
+        plt.title("Eigen Rays")
+        if len(ridxs) and self.zs[ridxs[-1]].size:
+            plt.ylim([self.zs[ridxs[-1]].min(), self.zs[ridxs[-1]].max()])
+
+    def plot_ducted(self, **kwargs):
+        """The eigenrays that never touch a boundary, all receiver depths (REF/ray_objects.py:587-602; the
+        reference plots -z here, depth positive down)."""
+        from matplotlib import pyplot as plt
+        kw = {"c": "k"}
+        kw.update(kwargs)
+        for ridx in self.ray_id.keys():
+            mask = (self.n_botts[ridx] == 0) & (self.n_surfs[ridx] == 0)
+            plt.plot(self.rs[ridx][mask].T, -self.zs[ridx][mask].T, **kw)
+        plt.xlabel("range [m]")
+        plt.ylabel("depth [m]")
+        plt.title("Ducted Eigen Rays")
+
+    def save_mat(self, filename):
+        """.mat export with the reference's schema (REF/ray_objects.py:604-636): one struct per receiver depth,
+        ``eigenrays.receiver_depth_<k>.{receiver_depth, xs, ts, zs, ps, received_angles, launch_angles, ray_id,
+        ray_id_int, n_bottom, n_surface, source_depth, num_eigenrays, num_eigenrays_found}``.  (The per-depth counts
+        are dictionaries in memory; MATLAB field names must be strings, so their keys are written as text.)"""
+        from scipy import io
+
+        def _fields(d):
+            return {("k_" + str(k).replace(".", "p").replace("-", "m")): v for k, v in dict(d).items()}
+        data = {}
+        for ridx, rdepth in enumerate(self.receiver_depths):
+            data[f"receiver_depth_{ridx}"] = {
+                "receiver_depth": rdepth, "xs": self.rs[ridx], "ts": self.ts[ridx], "zs": self.zs[ridx], "ps": self.ps[ridx],
+                "received_angles": self.received_angles[ridx], "launch_angles": self.launch_angles[ridx],
+                "ray_id": self.ray_id[ridx], "ray_id_int": self.ray_id_int[ridx],
+                "n_bottom": self.n_botts[ridx] if hasattr(self, "n_botts") else np.nan,
+                "n_surface": self.n_surfs[ridx] if hasattr(self, "n_surfs") else np.nan,
+                "source_depth": self.source_depths[ridx] if hasattr(self, "source_depths") else np.nan,
+                "num_eigenrays": _fields(self.num_eigenrays), "num_eigenrays_found": _fields(self.num_eigenrays_found)}
+        io.savemat(filename, {"eigenrays": data})
 
 
 __all__ = ["Ray", "RayFan", "EigenRays"]

@@ -394,6 +394,71 @@ def test_sharded_shoot_eigenrays_histogram_gloo_world2_equals_single_process(tmp
         for k in ref.files:
             assert np.array_equal(got[k], ref[k], equal_nan=True), (r, k)
 
+
+def test_eigenrays_export_and_plots(tmp_path):
+    """EigenRays.save_mat (schema of REF/ray_objects.py:604-636), plot / plot_ducted / plot_angle_time
+    (REF/ray_objects.py:550-602) on a hand-made result."""
+    import matplotlib
+    matplotlib.use("Agg")
+    from matplotlib import pyplot as plt
+    import scipy.io
+    import pygenray_amd as pr
+    from pygenray_amd.ray_objects import EigenRays, RayFan
+    z = np.arange(0, 5000, 10.0); r = np.linspace(0, 50e3, 6)
+    env = pr.OceanEnvironment2D(pr.DataArray(np.tile(pr.munk_ssp(z), (6, 1)), dims=["range", "depth"], coords={"range": r, "depth": z}),
+                                pr.DataArray(np.full(6, 4500.0), dims=["range"], coords={"range": r}), flat_earth_transform=False)
+    S = 9
+    rs = np.tile(np.linspace(0, 50e3, S), (3, 1))
+    fan0 = RayFan.from_arrays(np.array([-3.0, 1.0, 8.0]), rs, rs / 1500.0, -np.linspace(1000, 1200, S) * np.ones((3, 1)),
+                              np.array([[1e-4], [-1e-4], [2e-4]]) * np.cos(np.linspace(0, 6, S)), np.array([0, 0, 2]), np.array([0, 0, 1]),
+                              np.full(3, 1000.0))
+    fan1 = fan0[:1]
+    er = EigenRays([1000.0, 2000.0], {0: fan0, 1: fan1}, env, {1000.0: 4, 2000.0: 1}, {0: 3, 1: 1}, {0: [(2.0, 2.5)], 1: []})
+    assert er.received_angles[0].shape == (3,) and list(er.ray_id[0][:2]) != [] and er.ray_id[0][2].endswith("b")
+    path = str(tmp_path / "er.mat")
+    er.save_mat(path)
+    m = scipy.io.loadmat(path, squeeze_me=True, struct_as_record=False)["eigenrays"]
+    d0 = m.receiver_depth_0
+    for k in ("receiver_depth", "xs", "ts", "zs", "ps", "received_angles", "launch_angles", "ray_id", "ray_id_int", "n_bottom",
+              "n_surface", "source_depth", "num_eigenrays", "num_eigenrays_found"):
+        assert hasattr(d0, k), k
+    assert d0.receiver_depth == 1000.0 and np.array_equal(d0.zs, er.zs[0]) and np.array_equal(d0.launch_angles, er.launch_angles[0])
+    assert np.array_equal(d0.n_bottom, [0, 0, 2]) and m.receiver_depth_1.xs.shape == (S,)
+    for f in (lambda: er.plot(), lambda: er.plot(0, c="r"), lambda: er.plot([0, 1]), er.plot_ducted, lambda: er.plot_ducted(lw=2),
+              er.plot_angle_time, lambda: er.plot_angle_time([1])):
+        plt.figure(); f(); plt.close("all")
+    # plot_ducted draws only the rays that touched nothing, depth positive down
+    plt.figure(); er.plot_ducted()
+    lines = plt.gca().get_lines()
+    assert len(lines) == 2 + 1 and np.all(lines[0].get_ydata() > 0)
+    plt.close("all")
+
+
+def test_flat_earth_c_and_range_dependent_transform():
+    """flat_earth_c / OceanEnvironment2D.flat_earth_transform_rd (REF/environment.py:156-173, 239-303): column by column
+    eflat at the column's latitude, interpolated back onto the original depth grid (what xarray's interp does)."""
+    import scipy.interpolate
+    import pygenray_amd as pr
+    z = np.arange(0, 5500, 10.0); r = np.linspace(0, 200e3, 7); lat = np.linspace(20, 50, 7)
+    cv = np.array([pr.munk_ssp(z, 1300 + 1e-4 * ri) for ri in r])
+    for dims, vals in ((["range", "depth"], cv), (["depth", "range"], cv.T)):
+        c = pr.DataArray(vals, dims=dims, coords={"range": r, "depth": z, "lat": lat})
+        f = pr.flat_earth_c(c)
+        assert tuple(f.dims) == ("range", "depth") and f.values.shape == (7, len(z))
+        for i in (0, 3, 6):
+            depf, cf = pr.eflat(z, lat[i], cv[i])
+            want = scipy.interpolate.interp1d(depf, cf, bounds_error=False)(z)
+            np.testing.assert_allclose(f.values[i], want, rtol=1e-14, equal_nan=True)
+        assert np.all(f.values[:, 1:] > cv[:, 1:])          # the flattened speeds are larger at depth
+    env = pr.OceanEnvironment2D(c.transpose("range", "depth"), pr.DataArray(np.full(7, 5000.0), dims=["range"], coords={"range": r}),
+                                flat_earth_transform=False)
+    env.flat_earth_transform_rd()
+    assert np.array_equal(env.sound_speed_fe.values, f.values) and np.array_equal(env.bathymetry_fe.values, env.bathymetry.values)
+    arrs = pr._unpack_envi(env, flatearth=True)            # the 7-array contract takes it
+    assert arrs[0].shape == (7, len(z)) and np.array_equal(arrs[3], z)
+    with pytest.raises(ValueError):
+        pr.flat_earth_c(pr.DataArray(cv, dims=["range", "depth"], coords={"range": r, "depth": z}))
+
 def test_pack_and_interleave_single_process():
     import torch
     from pygenray_amd.distributed import pack_end_records, all_gather_fan, shard_indices
