@@ -98,7 +98,12 @@ struct FanArgs {
     uint32_t flags;
 };
 
-static_assert(alignof(FanArgs) == 8, "the fan kernel re-reads its FanArgs at kernel-argument offset 8");
+// The fan kernel's service phase and epilogue re-read FanArgs from the kernel-argument segment (so that what only they
+// need does not sit in SGPRs across the step loop): it is the kernel's SECOND argument, behind one pointer.
+constexpr int kFanArgsKernargOffset = 8;
+static_assert(sizeof(const EnvDev*) == kFanArgsKernargOffset && alignof(FanArgs) <= kFanArgsKernargOffset,
+              "pgr_fan_kernel(const EnvDev*, FanArgs): FanArgs must start at kernel-argument offset 8 -- change "
+              "kFanArgsKernargOffset together with the kernel's signature");
 
 #define RUNNING (-1)
 
@@ -853,6 +858,10 @@ struct Dense {
 // do.  An empty asm that takes the sums as operands keeps them in front of the branch.
 #define PGR_KEEP2(a_, b_) do { if (ZM == 5) asm volatile("" : "+v"(a_), "+v"(b_)); } while (0)
 #define PGR_KEEP6(a_, b_, c_, d_, e_, f_) do { if (ZM == 5) asm volatile("" : "+v"(a_), "+v"(b_), "+v"(c_), "+v"(d_), "+v"(e_), "+v"(f_)); } while (0)
+// hook behind the attempt's first table read (the fan kernel's deferred sample stores, HBM-table kernels)
+#ifndef PGR_AFTER_FIRST_FETCH
+#define PGR_AFTER_FIRST_FETCH() do { } while (0)
+#endif
 #define PGR_RK_STAGES(T_, H_)                                                                        \
     double k20, k21, k22, k30, k31, k32, k40, k41, k42, k50, k51, k52, k60, k61, k62, k70, k71, k72, \
         cs;                                                                                          \
@@ -869,6 +878,7 @@ struct Dense {
     const double zs2 = y1 + (f1 * vA21) * (H_), ps2 = y2 + (f2 * vA21) * (H_);                         \
     PGR_STAMP(3);                                                                                    \
     const auto ft2 = C.fetch(ir[0], zs2);                                                            \
+    PGR_AFTER_FIRST_FETCH();                                                                         \
     PGR_SB();                                                                                        \
     double a31 = f1 * vA31, a32 = f2 * vA31, a41 = f1 * vA41, a42 = f2 * vA41, a51 = f1 * vA51,           \
            a52 = f2 * vA51, a61 = f1 * vA61, a62 = f2 * vA61;                                           \

@@ -184,7 +184,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     constexpr bool save = (SAVE != 0);  // trajectories wanted (a.T != nullptr)
     const bool exact_samples = (SAVE == 2) && (a.flags & PGR_EXACT_SAMPLES) != 0;
     // (max_steps <= 2^30, host checked; the counters are ints)
-    const int attempt_limit = (int)((4 * a.max_steps + 4096 < 0x7fffffff) ? 4 * a.max_steps + 4096 : 0x7fffffff);
+    const int attempt_limit = (int)((4 * a.max_steps + 4096 < 0x3fffffff) ? 4 * a.max_steps + 4096 : 0x3fffffff);
     // PGR_STORED_SIGN: trajectories leave as pygenray stores them, z -> -z and p -> -p
     // (REF/ray_objects.py:51-52): a sign-bit xor, exact, and two host passes over 1.6 GB less
     const unsigned long long sgn = (a.flags & PGR_STORED_SIGN) ? 0x8000000000000000ULL : 0ULL;
@@ -212,7 +212,9 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     double pk_tnew = 0;
     unsigned pk_active = 0;
     int waited = 0;
-    int trips = 0, services = 0, fallbacks = 0;  // diagnostics (PGR_DEBUG_TRIPS)
+    // trips: the wave's trip count -- FUNCTIONAL: it gates the two step-count guards (no lane has made more attempts
+    // than the wave has made trips) -- and, with services / fallbacks, a PGR_DEBUG_TRIPS diagnostic
+    int trips = 0, services = 0, fallbacks = 0;
     const double min_step_bound = 10 * 0x1p-52 * fmax(fabs(a.x0), fabs(a.x1)) + 1e-300;  // see the attempt's head
     const int max_steps32 = (int)(a.max_steps < 0x7fffffff ? a.max_steps : 0x7fffffff);  // n_steps is an int
     const int guard_limit = (max_steps32 < attempt_limit ? max_steps32 : attempt_limit);
@@ -230,8 +232,37 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     // once per trip; an old value only narrows the window), else straight to global memory -- streaming stores
     // when the table lives in HBM / L2 (2.4 GB of samples per fan must not evict the table rows), plain ones with
     // the LDS table (measured faster there)
+    // DEFER (experiment, -DPGR_DEFER_STORES=1; HBM-table kernels that save trajectories): the sample a step produced
+    // is not stored where it is evaluated -- at the end of the attempt, in front of the next attempt's first table
+    // read, whose wait (vmcnt counts loads and stores in issue order) then waits for the three stores as well -- but
+    // held in registers and stored right BEHIND that read, so that the read's wait no longer covers them and they
+    // have a whole stage to retire.  MEASURED (round 3, configs[2], A/B in one gpurun call): 7.18 ms against 7.03 ms
+    // with the stores where they are evaluated -- like the LDS ring above, it removes a wait that is not the
+    // bottleneck and pays for it in registers.  Off.
+#ifndef PGR_DEFER_STORES
+#define PGR_DEFER_STORES 0
+#endif
+    constexpr bool DEFER = PGR_DEFER_STORES && !LDS_TAB && SAVE != 0 && !RINGK;
+    double pd_t = 0, pd_z = 0, pd_p = 0;
+    int pd_j = -1;   // sample index of the pending store, -1 = none
+    auto flush_pending = [&]() __attribute__((always_inline)) {
+        if (DEFER) {
+            if (pd_j >= 0) {
+                const int64_t o = (int64_t)pd_j * a.stride_smp;
+                __builtin_nontemporal_store(pd_t, &Tp[o]);
+                __builtin_nontemporal_store(pd_z, &Zp[o]);
+                __builtin_nontemporal_store(pd_p, &Pp[o]);
+                pd_j = -1;
+            }
+        }
+    };
     int rbase = 0;
     auto emit_sample = [&](int j, double vt, double vz, double vp) __attribute__((always_inline)) {
+        if (DEFER) {
+            flush_pending();   // (a step that owns two samples: the first goes out at once)
+            pd_t = vt; pd_z = vz; pd_p = vp; pd_j = j;
+            return;
+        }
         bool direct = true;
         if (RINGK) {
             const bool inr = (unsigned)(j - rbase) < (unsigned)ring_R;
@@ -333,6 +364,8 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
         asm volatile("" : "+v"(C.h_zc_g2));
         asm volatile("" : "+v"(C.h_zc_s1));
     }
+#undef PGR_AFTER_FIRST_FETCH
+#define PGR_AFTER_FIRST_FETCH() flush_pending()
     // One trip = one step attempt of every stepping lane, THEN the gate that decides whether the
     // wave services its parked lanes.  (The first trip only runs the gate: every lane starts with
     // need_init.)  The step comes first so that the common path -- nobody parked -- is the loop's
@@ -398,6 +431,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
             if (__builtin_expect(guards_due, 0)) {
                 const bool over = (n_rej + n_steps) > attempt_limit;
                 status = (reject & over) ? PGR_RAY_MAX_STEPS : status;
+                trips = trips < 0x7f000000 ? trips : 0x7f000000;   // (entered on every trip from here on: the counter cannot wrap)
             }
             PGR_STAMP(16);
 
@@ -506,8 +540,9 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                 const char __attribute__((address_space(4))) * ks_p =
                     (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
                 asm volatile("" : "+s"(ks_p));
-                const FanArgs __attribute__((address_space(4))) & as = *(const FanArgs __attribute__((address_space(4))) *)(ks_p + 8);
+                const FanArgs __attribute__((address_space(4))) & as = *(const FanArgs __attribute__((address_space(4))) *)(ks_p + kFanArgsKernargOffset);
                 const double svc_c_lo = es.c_lo, svc_c_hi = es.c_hi;
+                flush_pending();   // (the service may store the same sample index again: keep program order)
                 if (RINGK && ring_R > 0) rbase = ring_base[wv];
 #ifdef PGR_DBG_REPLAY
                 const unsigned long long dbg_s0 = __builtin_amdgcn_s_memtime();
@@ -935,6 +970,9 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
         }
     } while (ballot64(status == RUNNING) != 0);
 
+    flush_pending();
+#undef PGR_AFTER_FIRST_FETCH
+#define PGR_AFTER_FIRST_FETCH() do { } while (0)
     if (RINGK && ring_R > 0) {
         // every lane is through: the writer sends out what is left of this wave's rows.  A wave with a dropped ray
         // waits for that (its NaN columns below must land after the writer's rows; bounded, never a hang)
@@ -953,7 +991,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
         const char __attribute__((address_space(4))) * kp =
             (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(kp));
-        const FanArgs __attribute__((address_space(4))) & a = *(KArgs)(kp + 8);  // (shadows the argument)
+        const FanArgs __attribute__((address_space(4))) & a = *(KArgs)(kp + kFanArgsKernargOffset);  // (shadows the argument)
         if (save) {
             if (ok) {
                 // last column = exact final state (REF/launch_rays.py:775-777)

@@ -1618,9 +1618,16 @@ extern "C" int pgr_eigen_refine(pgr_env* env, int64_t nbk, const double* th1, co
     // one device block: 4 bracket arrays, theta, z_end, t_end (doubles), y0[3], end[3], 5 int arrays, the counter
     const size_t nd = (size_t)nbk;
     const size_t bytes = nd * 8 * (7 + 3 + 3) + nd * 4 * 6 + 256;
-    DevBuf buf;
-    if (buf.alloc(bytes)) return fail("pgr_eigen_refine: device allocation failed");
-    double* d = (double*)buf.p;
+    // (the environment's grow-only workspace -- the host-pointer fan entry's, which this call does not use: the
+    // many small searches of a receiver-depth loop pay no allocation)
+    if (bytes > env->ws_bytes) {
+        if (env->ws) (void)hipFree(env->ws);
+        env->ws = nullptr; env->ws_bytes = 0;
+        const size_t want = bytes > ((size_t)1 << 20) ? bytes : ((size_t)1 << 20);
+        if (hipMalloc(&env->ws, want) != hipSuccess) { env->ws = nullptr; return fail("pgr_eigen_refine: device allocation failed"); }
+        env->ws_bytes = want;
+    }
+    double* d = (double*)env->ws;
     EigenState e{};
     e.th1 = d; e.th2 = d + nd; e.z1 = d + 2 * nd; e.z2 = d + 3 * nd; e.theta = d + 4 * nd;
     e.z_end = d + 5 * nd; e.t_end = d + 6 * nd; e.y0 = d + 7 * nd;
@@ -1631,7 +1638,7 @@ extern "C" int pgr_eigen_refine(pgr_env* env, int64_t nbk, const double* th1, co
     e.state = ib + nd; e.n_trial = ib + 2 * nd;
     int32_t* nbott = ib + 3 * nd; int32_t* nsurf = ib + 4 * nd;
     e.n_active = ib + 5 * nd;
-    HIPCHK(hipMemsetAsync(buf.p, 0, bytes, st));
+    HIPCHK(hipMemsetAsync(env->ws, 0, bytes, st));
     HIPCHK(hipMemcpyAsync(e.th1, th1, nd * 8, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(e.th2, th2, nd * 8, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(e.z1, z1, nd * 8, hipMemcpyHostToDevice, st));

@@ -41,14 +41,23 @@ def ray_angle(x, y, cin, rin, zin):
     return theta, c
 
 
+_EVAL_ENVS = {}   # (ids + shapes of the tables) -> (EnvHandle, the arrays themselves: their ids stay theirs while we hold them)
+
+
 def _device_eval(x, y, cin, cpin, rin, zin, depths, depth_ranges):
+    """pgr_eval_points on the tables given; the uploaded environment is kept for the next scalar query on the same
+    arrays (the reference's event functions are called point by point: one table upload per call otherwise)."""
     from ._lib import EnvHandle
-    nb = len(depths)
-    env = EnvHandle(cin, cpin, rin, zin, depths, depth_ranges, np.zeros(nb))
-    try:
-        return env.eval_points(np.atleast_1d(np.asarray(x, float)), np.asarray(y, float).reshape(-1, 3))
-    finally:
-        env.close()
+    arrs = (cin, cpin, rin, zin, depths, depth_ranges)
+    key = tuple((id(a), getattr(a, "shape", None)) for a in arrs)
+    hit = _EVAL_ENVS.get(key)
+    if hit is None:
+        if len(_EVAL_ENVS) >= 4:
+            _, (old_env, _) = _EVAL_ENVS.popitem()
+            old_env.close()
+        nb = len(depths)
+        hit = _EVAL_ENVS[key] = (EnvHandle(cin, cpin, rin, zin, depths, depth_ranges, np.zeros(nb)), arrs)
+    return hit[0].eval_points(np.atleast_1d(np.asarray(x, float)), np.asarray(y, float).reshape(-1, 3))
 
 
 def derivsrd(x, y, cin, cpin, rin, zin, depths, depth_ranges):
