@@ -357,12 +357,19 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     // ZM == 5: a Horner step whose multiplier AND addend are wave-uniform costs a v_mov (one scalar operand per
     // VALU instruction): the addend of the first step of the index cubic and of the seed quadratic sit in VGPRs
     // (6 look-ups per attempt use them)
-#ifndef PGR_PIN_ZC
-#define PGR_PIN_ZC 1
+#ifndef PGR_PIN_ZC   // (A/B, flat-earth fan: all seven in VGPRs 6.86 vs 7.02 ms with trajectories, 5.78 vs 5.75 ms without)
+#define PGR_PIN_ZC (SAVE != 0 ? 2 : 1)
 #endif
     if (ZM == 5 && PGR_PIN_ZC) {
         asm volatile("" : "+v"(C.h_zc_g2));
         asm volatile("" : "+v"(C.h_zc_s1));
+    }
+    if (ZM == 5 && PGR_PIN_ZC >= 2) {   // all seven: the scalar file of the trajectory kernels is full of loop values already
+        asm volatile("" : "+v"(C.h_zc_g0));
+        asm volatile("" : "+v"(C.h_zc_g1));
+        asm volatile("" : "+v"(C.h_zc_g3));
+        asm volatile("" : "+v"(C.h_zc_s0));
+        asm volatile("" : "+v"(C.h_zc_s2));
     }
 #undef PGR_AFTER_FIRST_FETCH
 #define PGR_AFTER_FIRST_FETCH() flush_pending()
