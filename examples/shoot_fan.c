@@ -1,4 +1,5 @@
-/* Plain-C use of the C ABI (include/pgr.h): a 64-ray Munk fan to 100 km, end states only.
+/* Plain-C use of the C ABI (include/pgr.h): a 64-ray Munk fan to 100 km, end states only, through the host-pointer
+ * entry; then the same fan device resident (pgr_fan_*), its depth trajectories fetched afterwards.
  *
  *   gcc -std=c99 -Iinclude examples/shoot_fan.c -o shoot_fan -Lpygenray_amd/csrc -lpgr_hip -lm \
  *       -Wl,-rpath,$PWD/pygenray_amd/csrc
@@ -58,7 +59,31 @@ int main(void)
     for (int k = 0; k < N; k += 9)
         printf("ray %2d: status %d, T = %.9f s, z = %.6f m, %d steps, %d bottom / %d surface bounces\n", k, st[k],
                end[k][0], end[k][1], nsteps[k], nb[k], ns[k]);
+    /* The same fan with its results left in HBM (pgr_fan_*): the call returns while the kernel runs; the depth
+     * trajectories of the surviving rays are fetched afterwards, on their own ([S][M], PGR_COMPACT). */
+    enum { S = 11 };
+    pgr_fan* fan = NULL;
+    if (pgr_fan_launch(env, &y0[0][0], NULL, 0.0, 0.0, N, 0.0, 100e3, S, 1e-9, 1e-6, PGR_TERMINATE_BACKWARDS, 1000000, &fan)) {
+        fprintf(stderr, "pgr_fan_launch: %s\n", pgr_last_error());
+        return 1;
+    }
+    int64_t n_rays = 0, n_ok = 0;
+    double* zt = malloc(sizeof(double) * S * N);
+    double end2[N][3];
+    if (pgr_fan_wait(fan, &n_rays, &n_ok) || pgr_fan_fetch_rays(fan, &end2[0][0], NULL, NULL, NULL, NULL, NULL) ||
+        pgr_fan_fetch_samples(fan, NULL, zt, NULL, PGR_COMPACT)) {
+        fprintf(stderr, "pgr_fan_*: %s\n", pgr_last_error());
+        return 1;
+    }
+    int same = (n_rays == N);
+    for (int k = 0; k < N; k++) same = same && end2[k][0] == end[k][0] && end2[k][1] == end[k][1] && end2[k][2] == end[k][2];
+    /* all rays survive here, so column k of the compacted [S][M] block is ray k: its last row is the exact end state */
+    for (int k = 0; k < N && n_ok == N; k++) same = same && zt[(S - 1) * n_ok + k] == end[k][1];
+    printf("device-resident fan: %lld of %lld rays kept, %d samples each, equal to the host-entry fan: %s\n", (long long)n_ok,
+           (long long)n_rays, (int)S, same ? "yes" : "NO");
+    free(zt);
+    pgr_fan_destroy(fan);
     pgr_env_destroy(env);
     free(cin); free(cpin);
-    return 0;
+    return same ? 0 : 2;
 }

@@ -988,6 +988,7 @@ def test_plain_c_example_runs(lib, tmp_path):
     assert out.returncode == 0, out.stderr
     rows = re.findall(r"ray\s+(\d+): status (\d+), T = ([0-9.]+) s, z = ([-0-9.]+) m, (\d+) steps", out.stdout)
     assert len(rows) == 8
+    assert "device-resident fan: 64 of 64 rays kept, 11 samples each, equal to the host-entry fan: yes" in out.stdout
     arrs = munk_arrays(100e3, nr=20)
     th = -15.0 + 30.0 * np.arange(64) / 63
     y0 = y0_for(oracle, arrs, 1000.0, 0.0, th)

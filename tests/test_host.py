@@ -518,6 +518,44 @@ def test_committed_bench_line_and_profiles_are_well_formed():
         os.path.join(root, "profiles", "r02_config2_kernel_stats.csv")).read()
 
 
+
+def test_round3_profiles_name_the_binary_and_bench_line_carries_the_legs():
+    """profiles/r03_*: the PMC passes of the three kernels name the binary they describe (sha256 of the gfx950 machine
+    code, pgr_build_info(), git commit) and the committed bench line carries the legs, the lone-wave floor and counters
+    that belong to the code it ran."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tr = json.load(open(os.path.join(root, "profiles", "r03_traffic.json")))
+    assert len(tr["device_code_sha256"]) == 64 and tr["build"].startswith("layout: relaid") and len(tr["git_commit"]) == 40
+    for k in ("sample", "sample-nosave", "flatearth-sample", "flatearth-sample-nosave", "rangedep-sample", "rangedep-sample-nosave"):
+        assert tr[k]["rays"] == 100000 and tr[k]["hbm_gb_per_launch"] > 0, k
+    assert tr["sample"]["valu_wave_instructions_per_launch"] > 1e9 and tr["flatearth-sample"]["valu_wave_instructions_per_launch"] > 1e9
+    for v, tag in (("", "<true, 4, 1>"), ("_flatearth", "<true, 5, 1>"), ("_rangedep", "<false, 4, 1>")):
+        assert "pgr_fan_kernel" + tag in open(os.path.join(root, "profiles", f"r03_kernel_stats{v}.csv")).read(), v
+    d = json.load(open(os.path.join(root, "profiles", "r03_bench_line.json")))
+    for k in ("legs", "lone_wave_ms", "device_code_sha256", "roofline", "cpu_baseline", "cpu_baseline_c", "eigenray"):
+        assert k in d, k
+    assert set(d["legs"]) == {"flatearth_default", "range_dependent", "rays_1e6"}
+    for leg in ("flatearth_default", "range_dependent"):
+        for mode in ("end_state", "trajectories"):
+            assert d["legs"][leg][mode]["kernel_ms"] > 0 and 0 < d["legs"][leg][mode]["frac"] < 1
+    assert d["legs"]["flatearth_default"]["end_state"]["kernel_ms"] < 1.2 * d["lone_wave_ms"]["end_state"] * 1.1
+    assert d["cpu_baseline"]["jit"] is False and d["metric"].startswith("ray-steps/sec (whole node), 1e5-ray Munk fan")
+    # counters are reported only for the code they were taken with
+    if d["roofline"]["traffic"] is not None:
+        assert d["device_code_sha256"] == tr["device_code_sha256"]
+    else:
+        assert "device_code_sha256" in d["roofline"]["traffic_source"] or "no PMC pass" in d["roofline"]["traffic_source"]
+
+
+def test_device_code_hash_reads_the_built_library():
+    """_lib.device_code_sha256: the gfx950 .text inside the library's fat binary (no GPU needed)."""
+    from pygenray_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libpgr_hip.so not built")
+    h = _lib.device_code_sha256()
+    assert len(h) == 64 and h == _lib.device_code_sha256(_lib.LIB_PATH)
+
 # ----------------------------------------------------------------------------- build: instruction layout
 def test_instruction_layout_pass_plans_encodings():
     """pygenray_amd/_isa_layout.py: 4-byte e32 VALU instructions are re-encoded as 8-byte e64 ones
