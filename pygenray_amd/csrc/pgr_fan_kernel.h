@@ -360,11 +360,11 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
 #ifndef PGR_PIN_ZC   // (A/B, flat-earth fan: all seven in VGPRs 6.86 vs 7.02 ms with trajectories, 5.78 vs 5.75 ms without)
 #define PGR_PIN_ZC (SAVE != 0 ? 2 : 1)
 #endif
-    if (ZM == 5 && PGR_PIN_ZC) {
+    if (ZM == 5 && (PGR_PIN_ZC) >= 1) {
         asm volatile("" : "+v"(C.h_zc_g2));
         asm volatile("" : "+v"(C.h_zc_s1));
     }
-    if (ZM == 5 && PGR_PIN_ZC >= 2) {   // all seven: the scalar file of the trajectory kernels is full of loop values already
+    if (ZM == 5 && (PGR_PIN_ZC) >= 2) {   // all seven: the scalar file of the trajectory kernels is full of loop values already
         asm volatile("" : "+v"(C.h_zc_g0));
         asm volatile("" : "+v"(C.h_zc_g1));
         asm volatile("" : "+v"(C.h_zc_g3));
