@@ -75,11 +75,30 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
 #define PGR_SAMPLE_RING 0
 #endif
     constexpr bool RINGK = PGR_SAMPLE_RING && !LDS_TAB && SAVE != 0;
+    // ---- the wave's row ring (LDS-table kernels that save trajectories, sample-major output) ----
+    // A wave's 64 rays own sample row j in different trips, so the lanes' own stores hit each 128-byte line of a row
+    // two or three times, in pieces.  Measured (round 3, `-DPGR_STORE_EXPERIMENT`, headline fan): samples evaluated and
+    // never stored 5.41 ms; stored, every lane to row 0 -- the same store instructions, four full lines each -- 5.45 ms;
+    // stored where they belong 5.76 ms: the pieces cost 0.3 ms, 5 % of the fan.  So the lanes drop (T, z, p) of row j
+    // into the wave's LDS ring (row j mod R, beside the table) and the WAVE stores row j once -- three 512-byte stores,
+    // row address in SGPRs -- when no lane can write it any more: every running lane has jnext >= j + 2 (a lane's later
+    // writes, the re-sample after a bounce included, have index >= jnext - 1).  A lane more than R rows ahead of the
+    // wave's slowest stores that sample itself and leaves the ring entry empty (sentinel).
+    // MEASURED (same round, headline fan, A/B inside one library): ring on 6.22 ms, off 5.82 ms; the lone steepest wave
+    // 5.79 against 5.41 ms -- about 350 cycles per trip for the window test, three ds_write per sample, the
+    // completeness ballot and, on six trips in ten, three ds_read whose latency nothing covers plus the row's
+    // stores: more than the pieces cost.  Bit-identical (scripts/regress.py); NOT compiled into the product
+    // (-DPGR_WAVE_RING=1 builds it, PGR_OPT_WAVE_RING switches it at run time then).
+#ifndef PGR_WAVE_RING
+#define PGR_WAVE_RING 0
+#endif
+    constexpr bool WRING = PGR_WAVE_RING && LDS_TAB && SAVE != 0;
     const int wv = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
     const int ring_R = RINGK ? a.ring_rows : 0;
     const int n_cw = (int)(blockDim.x >> 6) - (ring_R > 0 ? 1 : 0);   // integrating waves of this workgroup
     // (explicit LDS pointers: a volatile access through a generic pointer is a flat_load / flat_store, which counts
     // in vmcnt like any global access -- the very coupling the ring is there to remove)
+    const unsigned long long RING_EMPTY = 0x7ff8dead5a5a0001ULL;     // a NaN no arithmetic produces
     typedef volatile int __attribute__((address_space(3))) * LdsIntP;
     typedef volatile double __attribute__((address_space(3))) * LdsDblP;
     typedef __attribute__((address_space(3))) char* LdsCharP;
@@ -87,7 +106,11 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     const LdsIntP ring_base = ring_pub + n_cw * 64;            // [16] first row of each wave still in its ring
     const LdsIntP ring_done = ring_base + 16;                  // [16] wave's rows all written out
     const LdsDblP ring_data = (LdsDblP)(ring_base + 64);       // [n_cw][R][3][64]
-    const unsigned long long RING_EMPTY = 0x7ff8dead5a5a0001ULL;     // a NaN no arithmetic produces
+    const int wr_R = WRING ? a.ring_rows : 0;                       // rows per wave (a power of two) or 0
+    const LdsDblP wr_all = (LdsDblP)((LdsCharP)(char*)lds_tab + (WRING ? a.ring_lds_off : 0));   // [waves][R][3][64]
+    if (wr_R > 0)
+        for (int k = threadIdx.x; k < (int)(blockDim.x >> 6) * wr_R * 192; k += blockDim.x)
+            wr_all[k] = __longlong_as_double((long long)RING_EMPTY);
     if (ring_R > 0) {
         for (int k = threadIdx.x; k < n_cw * 64; k += blockDim.x) ring_pub[k] = 0;
         for (int k = threadIdx.x; k < 64; k += blockDim.x) ring_base[k] = 0;   // (base and done)
@@ -256,7 +279,24 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
             }
         }
     };
+#ifdef PGR_STORE_EXPERIMENT
+    long long sink = 0;
+#endif
     int rbase = 0;
+    int wr_base = 0;                                                 // first row of this wave not yet stored (wave-uniform)
+    const LdsDblP wr_mine = wr_all + (wv * wr_R * 192 + lane_id);     // this lane's column of the wave's ring
+    // the wave stores ring row `row` (a wave-uniform index): lanes whose entry is not the sentinel, then the entries are
+    // emptied.  Row address in scalar registers, the lane's part of it is its ray's offset.
+    auto wr_store_row = [&](int row) __attribute__((always_inline)) {
+        const LdsDblP e = wr_mine + (((row & (wr_R - 1)) * 3) * 64);
+        const double vt = e[0];
+        if ((unsigned long long)__double_as_longlong(vt) != RING_EMPTY) {
+            const double vz = e[64], vp = e[128];
+            const int64_t o = (int64_t)row * a.stride_smp;
+            Tp[o] = vt; Zp[o] = vz; Pp[o] = vp;
+            e[0] = __longlong_as_double((long long)RING_EMPTY);
+        }
+    };
     auto emit_sample = [&](int j, double vt, double vz, double vp) __attribute__((always_inline)) {
         if (DEFER) {
             flush_pending();   // (a step that owns two samples: the first goes out at once)
@@ -264,6 +304,14 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
             return;
         }
         bool direct = true;
+        if (WRING) {
+            const bool inr = (unsigned)(j - wr_base) < (unsigned)wr_R;
+            direct = !inr;
+            if (inr) {
+                const LdsDblP e = wr_mine + (((j & (wr_R - 1)) * 3) * 64);
+                e[0] = vt; e[64] = vz; e[128] = vp;
+            }
+        }
         if (RINGK) {
             const bool inr = (unsigned)(j - rbase) < (unsigned)ring_R;
             direct = !inr;
@@ -272,9 +320,15 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                 e[0] = vt; e[64] = vz; e[128] = vp;
             }
         }
-        if (!RINGK || __builtin_expect(ballot64(direct) != 0, 0)) {
+        if (!(RINGK || WRING) || __builtin_expect(ballot64(direct) != 0, 0)) {
             if (direct) {
+#ifdef PGR_STORE_EXPERIMENT   // timing experiments only (wrong trajectories): 1 = samples evaluated, never stored (folded into a
+                              // value the epilogue stores once); 2 = every sample stored to row 0 (same instructions, no new lines)
+                if (PGR_STORE_EXPERIMENT == 1) { sink ^= __double_as_longlong(vt) ^ __double_as_longlong(vz) ^ __double_as_longlong(vp); return; }
+                const int64_t o = (PGR_STORE_EXPERIMENT == 2) ? 0 : (int64_t)j * a.stride_smp;
+#else
                 const int64_t o = (int64_t)j * a.stride_smp;
+#endif
                 if (LDS_TAB) { Tp[o] = vt; Zp[o] = vz; Pp[o] = vp; }
                 else {
                     __builtin_nontemporal_store(vt, &Tp[o]);
@@ -526,6 +580,13 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
         if (RINGK && ring_R > 0) ring_pub[wv * 64 + lane_id] = run ? jnext : 0x7fffffff;
         pend = run && (parked || need_init);
         pm = ballot64(pend);
+        if (WRING && wr_R > 0) {
+            // row wr_base is complete when every running lane has jnext >= wr_base + 2
+            if (wr_base < S - 1 && ballot64(run && jnext < wr_base + 2) == 0 && ballot64(run) != 0) {
+                wr_store_row(wr_base);
+                wr_base++;
+            }
+        }
         } while (pm == 0 && ballot64(run) != 0);
         // keep ONE exit of the trip loop: without this the compiler threads "left with pm != 0" straight
         // to the gate and gives the loop two exits, whose unification costs the common path two more
@@ -978,6 +1039,11 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     } while (ballot64(status == RUNNING) != 0);
 
     flush_pending();
+    if (WRING && wr_R > 0) {
+        // every lane is through: the rows still in the ring go out (rows beyond the window were stored by their lanes)
+        const int top = (wr_base + wr_R < S - 1) ? wr_base + wr_R : S - 1;
+        for (int row = wr_base; row < top; row++) wr_store_row(row);
+    }
 #undef PGR_AFTER_FIRST_FETCH
 #define PGR_AFTER_FIRST_FETCH() do { } while (0)
     if (RINGK && ring_R > 0) {
@@ -1027,6 +1093,9 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                 a.end_state[3 * ray + 2] = ok ? y2 : nan;
             }
         }
+#ifdef PGR_STORE_EXPERIMENT
+        if (save && sink == 0x123456789LL) nb++;   // (keeps the folded samples alive)
+#endif
         a.n_bott[ray] = nb;
         a.n_surf[ray] = ns;
         a.status[ray] = status;

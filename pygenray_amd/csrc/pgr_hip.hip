@@ -241,6 +241,7 @@ struct pgr_env {
     int park_lanes = 64, park_trips = 10;
     int place = 2;                    // 0 off, 1 issue priorities only, 2 cost-aware placement + priorities
     int ring_sleep = 2;
+    int wave_ring = PGR_WAVE_RING;    // (experiment) LDS-table trajectory kernels: samples leave as full rows through the wave's LDS ring
     int sample_ring = PGR_SAMPLE_RING, ring_rows = 0;  // HBM-table kernels with trajectories: LDS sample ring + writer wave (rows: 0 = automatic)
     hipStream_t stream = nullptr;     // the host-pointer entry's own stream (created on first use)
     EnvDev d{};
@@ -344,6 +345,11 @@ extern "C" int pgr_env_set_option(pgr_env* env, int what, int a, int b)
     case PGR_OPT_PLACEMENT:
         if (a < 0 || a > 2) return fail("placement: 0 = off, 1 = priorities only, 2 = placement + priorities");
         env->place = a;
+        return 0;
+    case PGR_OPT_WAVE_RING:
+        if (a < 0 || a > 1) return fail("wave ring: 0 = off, 1 = on");
+        if (a != 0 && !PGR_WAVE_RING) return fail("wave ring: this library was built without it (-DPGR_WAVE_RING=1)");
+        env->wave_ring = a;
         return 0;
     case PGR_OPT_SAMPLE_RING:
         if (a != 0 && !PGR_SAMPLE_RING) return fail("sample ring: this library was built without it (-DPGR_SAMPLE_RING=1)");
@@ -874,6 +880,15 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
     // the sample ring behind that: per integrating wave 256 B of published sample indices and R rows of
     // 64 x (T, z, p); one more 256 B block of row counters.  R = the largest of 16, 8, 4 that fits.
     a.ring_lds_off = 0; a.ring_rows = 0; a.ring_sleep = env->ring_sleep;
+    if (lds_tab && save && (flags & PGR_SAMPLE_MAJOR) && env->wave_ring) {
+        // the wave's row ring of the LDS-table trajectory kernels (pgr_fan_kernel.h): R rows of 64 x (T, z, p) per wave
+        // behind everything else, when that much LDS is left (R = 8 or 4)
+        const size_t at = (lds + 15) & ~(size_t)15;
+        for (int R = 8; R >= 4; R >>= 1) {
+            const size_t need = (size_t)wpb * R * 1536;
+            if (at + need <= env->max_lds) { a.ring_lds_off = (int)at; a.ring_rows = R; lds = at + need; break; }
+        }
+    }
     if (want_ring) {
         const size_t at = (lds + 15) & ~(size_t)15;
         for (int R = 16; R >= 4; R >>= 1) {

@@ -599,6 +599,34 @@ def test_full_size_default_flat_earth_environment(lib):
     assert np.array_equal(fan.n_botts, a["n_bott"][keep])
 
 
+def test_cubic_index_estimate_qualifies_only_smooth_grids(lib):
+    """pgr_env_create verifies the cubic index estimate node by node (fit_cubic_index): the flat-earth map of a uniform
+    grid and a linspace grid that is not bitwise uniform qualify; a power-law stretch, a grid with a kink and a random
+    grid do not (they keep the three-node / bin-table / binary search) -- and all of them integrate to the oracle's bits."""
+    import pygenray_amd as pr
+    rng = np.random.default_rng(7)
+    zu = np.arange(0, 5600, 2.0)
+    grids = {
+        "flat-earth of arange": (pr.eflat(zu, 35.0)[0], 1),
+        "flat-earth at 80 N": (pr.eflat(zu, 80.0)[0], 1),
+        "linspace, not bitwise uniform": (np.linspace(0, 5600.3, 2801), 1),
+        "power-law stretch": (5600 * np.linspace(0, 1, 1500) ** 1.5, 0),
+        "kinked": (np.concatenate([np.linspace(0, 1000, 500), np.linspace(1000, 5600, 800)[1:]]), 0),
+        "random": (np.sort(np.concatenate([[0, 5600], rng.uniform(0, 5600, 1200)])), 0),
+        "uniform (closed form, no estimate needed)": (zu, 0),
+    }
+    r = np.linspace(0, 80e3, 12)
+    th = np.linspace(-16, 16, 96)
+    for name, (z, want) in grids.items():
+        cin = np.tile(munk(z), (len(r), 1))
+        arrs = [cin, np.gradient(cin, z, axis=1, edge_order=1), r, z, np.full(12, 5000.0), r.copy(), np.zeros(12)]
+        env = lib.EnvHandle(*arrs)
+        assert env.query(5) == want, name
+        env.close()
+        y0 = y0_for(oracle, arrs, 900.0, 0.0, th)
+        gpu_vs_oracle(lib, arrs, y0, 0.0, 80e3, 17, label=name)
+
+
 def test_arithmetic_building_blocks(lib):
     """The kernel's divide / sqrt expansions must be correctly rounded on the operand ranges that
     occur (they replace the compiler's IEEE expansions), 10*ulp(t) exact, and the three libm
