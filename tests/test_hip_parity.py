@@ -601,7 +601,7 @@ def test_full_size_default_flat_earth_environment(lib):
 
 def test_cubic_index_estimate_qualifies_only_smooth_grids(lib):
     """pgr_env_create verifies the cubic index estimate node by node (fit_cubic_index): the flat-earth map of a uniform
-    grid and a linspace grid that is not bitwise uniform qualify; a power-law stretch, a grid with a kink and a random
+    grid and a grid of accumulated steps (linear up to rounding, not bitwise uniform) qualify; a power-law stretch, a grid with a kink and a random
     grid do not (they keep the three-node / bin-table / binary search) -- and all of them integrate to the oracle's bits."""
     import pygenray_amd as pr
     rng = np.random.default_rng(7)
@@ -609,7 +609,7 @@ def test_cubic_index_estimate_qualifies_only_smooth_grids(lib):
     grids = {
         "flat-earth of arange": (pr.eflat(zu, 35.0)[0], 1),
         "flat-earth at 80 N": (pr.eflat(zu, 80.0)[0], 1),
-        "linspace, not bitwise uniform": (np.linspace(0, 5600.3, 2801), 1),
+        "accumulated steps: linear to rounding, not bitwise j * dz": (np.cumsum(np.r_[0.0, np.full(2800, 2.0001)]), 1),
         "power-law stretch": (5600 * np.linspace(0, 1, 1500) ** 1.5, 0),
         "kinked": (np.concatenate([np.linspace(0, 1000, 500), np.linspace(1000, 5600, 800)[1:]]), 0),
         "random": (np.sort(np.concatenate([[0, 5600], rng.uniform(0, 5600, 1200)])), 0),
