@@ -9,7 +9,6 @@ iteration is ONE fan launch holding the trial rays of all still-active brackets.
 """
 import numpy as np
 
-from .launch_rays import _shoot_ode_angles
 from .ray_objects import RayFan, EigenRays
 
 # diagnostics of the last find_eigenrays call (bench.py reports them): fan launches and trial rays
