@@ -289,6 +289,11 @@ def main(argv=None):
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # PGR_BENCH_ONE_GPU=1 (rehearsal on a one-GPU box, with --backend gloo): every rank drives device 0.  The N > 1 code path
+    # runs for real -- strided shards, packed end records, all-gather, sharded eigenray search -- but the ranks share one
+    # GPU, so the line it prints is a functional check, never a scaling number (it says so in `config.sharding`)
+    one_gpu = os.environ.get("PGR_BENCH_ONE_GPU") == "1"
+    dev_index = 0 if one_gpu else local_rank
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         # launched under an external torchrun with a different rank count: the JSON line must not lie
@@ -325,7 +330,7 @@ def main(argv=None):
     from pygenray_amd.device_fan import DeviceFan, fan_y0
     from pygenray_amd.distributed import shard_indices, start_all_gather_records, arrival_time_histogram
 
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(dev_index)
     # PGR_BENCH_FORCE_DIST=1 rehearses the N > 1 code path (RCCL init, all-gather, reductions)
     # with a single rank on a one-GPU box
     use_dist = world > 1 or os.environ.get("PGR_BENCH_FORCE_DIST") == "1"
@@ -337,7 +342,10 @@ def main(argv=None):
                 sk.bind(("127.0.0.1", 0))
                 os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
             os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
-        dist.init_process_group(args.backend, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(args.backend, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.backend)
         joined = torch.ones(1, device="cuda")
         dist.all_reduce(joined)
         if int(joined.item()) != world:
@@ -349,7 +357,7 @@ def main(argv=None):
         from pygenray_amd.environment import _unpack_envi
         env_obj.flat_earth_transform(lat=35)
         arrs = _unpack_envi(env_obj, flatearth=True)
-    env = _lib.EnvHandle(*arrs, device=local_rank)
+    env = _lib.EnvHandle(*arrs, device=dev_index)
     if args.waves_per_block:
         env.set_option("waves_per_block", args.waves_per_block)
     n_global = args.rays * world
@@ -427,10 +435,10 @@ def main(argv=None):
         for _ in range(2):   # second run: tables resident, buffers allocated
             fence()
             t_a = time.perf_counter()
-            gfan = shoot_rays_sharded(SOURCE_DEPTH, 0.0, angles, RANGE_M, env_obj, flatearth=False, device=local_rank)
+            gfan = shoot_rays_sharded(SOURCE_DEPTH, 0.0, angles, RANGE_M, env_obj, flatearth=False, device=dev_index)
             t_b = time.perf_counter()
             ger = find_eigenrays_sharded(gfan, [1000.0], SOURCE_DEPTH, 0.0, RANGE_M, 2, env_obj, ztol=1, max_iter=20,
-                                         debug=False, flatearth=False, quiet=True, device=local_rank)
+                                         debug=False, flatearth=False, quiet=True, device=dev_index)
             fence()
             t_c = time.perf_counter()
         tt = torch.tensor([t_c - t_a, t_b - t_a], dtype=torch.float64, device="cuda")
@@ -494,7 +502,9 @@ def main(argv=None):
                        "trajectory_layout": args.layout if save else "none",
                        "ray_steps_per_pass": total_steps, "dropped_rays": n_drop,
                        "histogram_bins": HIST_BINS if args.histogram else 0,
-                       "sharding": "strided launch angles, all-gather of end records" if world > 1 else "single GPU"},
+                       "sharding": ("strided launch angles, all-gather of end records" + (" -- REHEARSAL: all ranks share ONE GPU "
+                                    f"(PGR_BENCH_ONE_GPU, backend {args.backend}); not a scaling number" if one_gpu else ""))
+                                   if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_gb_per_launch": traffic_gb, "traffic_source": tnote,

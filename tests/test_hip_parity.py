@@ -937,6 +937,72 @@ def test_many_fans_in_flight_on_user_streams_keep_their_wave_maps(lib):
     env.close()
 
 
+_TWO_RANK_WORKER = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+import pygenray_amd as pr
+from pygenray_amd.distributed import shoot_rays_sharded, find_eigenrays_sharded, arrival_histogram_sharded
+rank = int(sys.argv[1])
+torch.cuda.set_device(0)                     # both ranks share the box's one GPU: the collective goes through gloo
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=rank, world_size=2)
+z = np.arange(0, 6000, 1.0); r = np.linspace(0, 100e3, 100)
+env = pr.OceanEnvironment2D(pr.DataArray(np.tile(pr.munk_ssp(z), (100, 1)), dims=["range", "depth"], coords={"range": r, "depth": z}),
+                            pr.DataArray(np.full(100, 5000.0), dims=["range"], coords={"range": r}), flat_earth_transform=False)
+theta = np.linspace(-19.9, 19.9, 2001)
+fan = shoot_rays_sharded(1000.0, 0.0, theta, 100e3, env, flatearth=False, device=0)
+er = find_eigenrays_sharded(fan, [800.0, 1000.0], 1000.0, 0.0, 100e3, 41, env, debug=False, flatearth=False, quiet=True, device=0)
+h, edges = arrival_histogram_sharded(1000.0, 0.0, theta, 100e3, env, 64, 66.0, 68.0, flatearth=False, device=0)
+out = dict(thetas=fan.thetas, ts=fan.ts, zs=fan.zs, ps=fan.ps, nb=fan.n_botts, ns=fan.n_surfs, hist=h)
+for k in (0, 1):
+    out[f"e{k}_th"] = er.launch_angles[k]; out[f"e{k}_ts"] = er.ts[k]; out[f"e{k}_zs"] = er.zs[k]; out[f"e{k}_nb"] = er.n_botts[k]
+    out[f"e{k}_failed"] = np.array(er.failed_eray_theta_brackets[k], dtype=float).reshape(-1, 2)
+np.savez(sys.argv[2], **out)
+dist.barrier(); dist.destroy_process_group()
+print("RANK_OK")
+"""
+
+
+def test_sharded_api_two_ranks_on_one_gpu_equal_the_single_process_api(lib, tmp_path):
+    """The sharded path with the REAL HIP fan and the real device refinement on TWO ranks: both processes drive this
+    box's one GPU (the kernel writes the packed end records, each rank refines its share of the brackets with
+    pgr_eigen_refine), the collectives go through gloo (RCCL wants one GPU per rank).  Every rank's fan, EigenRays and
+    histogram equal pr.shoot_rays / pr.find_eigenrays / np.histogram in this process, to the bit."""
+    import socket
+    import subprocess
+    import sys
+    import os
+    import pygenray_amd as pr
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    w = tmp_path / "worker.py"
+    w.write_text(_TWO_RANK_WORKER % dict(root=root, port=port))
+    procs = [subprocess.Popen([sys.executable, str(w), str(rk), str(tmp_path / f"rank{rk}.npz")], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for rk in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0 and "RANK_OK" in o, e[-3000:]
+    z = np.arange(0, 6000, 1.0); r = np.linspace(0, 100e3, 100)
+    env = pr.OceanEnvironment2D(pr.DataArray(np.tile(pr.munk_ssp(z), (100, 1)), dims=["range", "depth"], coords={"range": r, "depth": z}),
+                                pr.DataArray(np.full(100, 5000.0), dims=["range"], coords={"range": r}), flat_earth_transform=False)
+    theta = np.linspace(-19.9, 19.9, 2001)
+    ref = pr.shoot_rays(1000.0, 0.0, theta, 100e3, 3, env, debug=False, flatearth=False)
+    er1 = pr.find_eigenrays(ref, [800.0, 1000.0], 1000.0, 0.0, 100e3, 41, env, debug=False, flatearth=False, quiet=True)
+    want_h = np.histogram(ref.ts[:, -1], bins=64, range=(66.0, 68.0))[0]
+    for rk in range(2):
+        g = np.load(tmp_path / f"rank{rk}.npz")
+        assert np.array_equal(g["thetas"], ref.thetas) and np.array_equal(g["zs"][:, 0], ref.zs[:, -1])
+        assert np.array_equal(g["ts"][:, 0], ref.ts[:, -1]) and np.array_equal(g["ps"][:, 0], ref.ps[:, -1])
+        assert np.array_equal(g["nb"], ref.n_botts) and np.array_equal(g["ns"], ref.n_surfs) and np.array_equal(g["hist"], want_h)
+        for k in (0, 1):
+            assert len(g[f"e{k}_th"]) == er1.num_eigenrays_found[k] >= 3
+            assert np.array_equal(g[f"e{k}_th"], er1.launch_angles[k]) and np.array_equal(g[f"e{k}_zs"], er1.zs[k])
+            assert np.array_equal(g[f"e{k}_ts"], er1.ts[k]) and np.array_equal(g[f"e{k}_nb"], er1.n_botts[k])
+            assert np.array_equal(g[f"e{k}_failed"], np.array(er1.failed_eray_theta_brackets[k], dtype=float).reshape(-1, 2))
+
+
 def test_arrival_time_histogram_equals_numpy(lib):
     """pgr_arrival_histogram_device (BASELINE configs[4]) against np.histogram, count for count:
     values on bin edges and on the range ends, NaN, dropped rays, strided views, packed end records."""
