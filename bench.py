@@ -194,7 +194,7 @@ def _noop(_):
     return 0
 
 
-def kernel_leg(arrs, n_rays, save, passes=4, amin=-20.0, amax=20.0, rays_lo=None):
+def kernel_leg(arrs, n_rays, save, passes=6, amin=-20.0, amax=20.0, rays_lo=None):
     """One more workload through the same device entry, a few passes: kernel time from HIP events on the launch
     stream, accepted steps, the contract's algorithmic bytes and the fraction of the HBM peak they amount to."""
     import torch
@@ -206,7 +206,8 @@ def kernel_leg(arrs, n_rays, save, passes=4, amin=-20.0, amax=20.0, rays_lo=None
     env = _lib.EnvHandle(*arrs)
     y0 = fan_y0(arrs, SOURCE_DEPTH, 0.0, -theta)
     fan = DeviceFan(env, y0, 0.0, RANGE_M, S_SAVE, save=save, sample_major=True)
-    fan.run()
+    for _ in range(3):     # (the clock has dropped while the host built this leg's tables: let it come back)
+        fan.run()
     torch.cuda.synchronize()
     ts = []
     for _ in range(passes):
@@ -218,7 +219,7 @@ def kernel_leg(arrs, n_rays, save, passes=4, amin=-20.0, amax=20.0, rays_lo=None
     steps = fan.ray_steps()
     alive = max(fan.N - int((fan.status != 0).sum().item()), 1)
     b_alg = 80.0 + (24.0 * S_SAVE / (steps / alive) if save else 0.0)
-    out = {"kernel_ms": ms, "frac": steps * b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ray_steps": steps,
+    out = {"kernel_ms": ms, "kernel_ms_min": float(np.min(ts)), "frac": steps * b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ray_steps": steps,
            "ray_steps_per_s": steps / (ms * 1e-3), "bytes_per_ray_step": b_alg, "passes": passes}
     del fan
     env.close()
