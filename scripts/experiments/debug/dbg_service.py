@@ -1,7 +1,7 @@
 """Where a bounce service spends its cycles (library built with -DPGR_DBG_REPLAY: scripts/build_variants.py dbgreplay):
 s_memtime stamps accumulated over the services of one wave of steep rays."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 from helpers import munk_arrays
