@@ -98,6 +98,9 @@ int pgr_env_create(pgr_env** env, int device, const double* cin, const double* c
                    const double* rin, const double* zin, int64_t nr, int64_t nz,
                    const double* depths, const double* depth_ranges, const double* bottom_angles,
                    int64_t nb);
+/* Releases the tables, workspaces and stream.  While device-resident fans (pgr_fan_launch below) of this
+ * environment are alive the release is deferred to the pgr_fan_destroy of the last of them; the handle must not be
+ * used for new calls after pgr_env_destroy either way. */
 void pgr_env_destroy(pgr_env* env);
 
 /* Properties the kernel selection depends on (for tests / diagnostics):

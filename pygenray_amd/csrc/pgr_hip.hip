@@ -254,6 +254,10 @@ struct pgr_env {
     // more than the kernel's launch; hipFree also waits for the whole device): at most 4 buffers / 64 GB
     std::vector<std::pair<void*, size_t>> fan_pool;
     std::mutex fan_pool_mutex;
+    // device-resident fans (pgr_fan_*) that still point at this environment, and whether pgr_env_destroy has been called
+    // meanwhile (the last fan to go then releases the environment): both under fan_pool_mutex
+    int live_fans = 0;
+    bool doomed = false;
     void* stage = nullptr;   // page-locked host staging of the compacted per-ray fetch (grow-only)
     size_t stage_bytes = 0;
     void* ws2 = nullptr;   // second grow-only workspace: the compacted trajectories of PGR_COMPACT
@@ -526,9 +530,8 @@ static int upload(pgr_env* e, const T* host, size_t count, const T** dev)
     return 0;
 }
 
-extern "C" void pgr_env_destroy(pgr_env* env)
+static void env_release(pgr_env* env)
 {
-    if (!env) return;
     (void)hipSetDevice(env->device);
     for (void* p : env->allocs) (void)hipFree(p);
     for (auto& ps : env->place_slots) {
@@ -541,6 +544,16 @@ extern "C" void pgr_env_destroy(pgr_env* env)
     for (auto& pb : env->fan_pool) (void)hipFree(pb.first);
     if (env->stream) (void)hipStreamDestroy(env->stream);
     delete env;
+}
+
+extern "C" void pgr_env_destroy(pgr_env* env)
+{
+    if (!env) return;
+    {
+        std::lock_guard<std::mutex> lock(env->fan_pool_mutex);
+        if (env->live_fans > 0) { env->doomed = true; return; }   // its fans still use its stream and tables: the last one releases it
+    }
+    env_release(env);
 }
 
 extern "C" int pgr_env_create(pgr_env** out, int device, const double* cin, const double* cpin,
@@ -1043,9 +1056,13 @@ struct OrderedPrefault {
         while ((v = reg[k].load(std::memory_order_acquire)) < 2) std::this_thread::yield();
         return v;
     }
+    hipStream_t stream = nullptr;       // the copies' stream, once one has been enqueued
+    bool stream_used = false;
     ~OrderedPrefault()
     {
         for (auto& t : th) t.join();
+        // (an error return between two copies gets here with DMAs still in flight: never unlock memory under them)
+        if (stream_used) (void)hipStreamSynchronize(stream);
         for (size_t k = 0; k < jobs.size(); k++)
             if (reg[k].load() == 2) (void)hipHostUnregister(jobs[k].dst);
     }
@@ -1083,6 +1100,7 @@ static int d2h_pipelined(std::vector<D2HJob> jobs, hipStream_t st, int device, R
         jobs = cut;
     }
     OrderedPrefault pf(jobs, device);
+    pf.stream = st;
     unsigned nt = std::thread::hardware_concurrency();
     nt = nt < 1 ? 1 : (nt > 16 ? 16 : nt);
     pf.run(nt);
@@ -1101,6 +1119,7 @@ static int d2h_pipelined(std::vector<D2HJob> jobs, hipStream_t st, int device, R
             live[j].bytes = o >= whole[k].bytes ? 0 : (whole[k].bytes - o < jobs[j].bytes ? whole[k].bytes - o : jobs[j].bytes);
         }
     }
+    pf.stream_used = true;
     for (size_t k = 0; k < live.size(); k++) {
         const D2HJob& q = live[k];
         if (q.bytes == 0) continue;
@@ -1317,16 +1336,22 @@ struct pgr_fan {
 extern "C" void pgr_fan_destroy(pgr_fan* f)
 {
     if (!f) return;
-    (void)hipSetDevice(f->env->device);
+    pgr_env* env = f->env;
+    (void)hipSetDevice(env->device);
     if (f->done) { (void)hipEventSynchronize(f->done); (void)hipEventDestroy(f->done); }
-    if (f->buf) {
-        std::lock_guard<std::mutex> lock(f->env->fan_pool_mutex);
-        size_t held = 0;
-        for (auto& pb : f->env->fan_pool) held += pb.second;
-        if (f->env->fan_pool.size() < 4 && held + f->buf_bytes <= ((size_t)64 << 30)) f->env->fan_pool.emplace_back(f->buf, f->buf_bytes);
-        else (void)hipFree(f->buf);
+    bool last = false;
+    {
+        std::lock_guard<std::mutex> lock(env->fan_pool_mutex);
+        if (f->buf) {
+            size_t held = 0;
+            for (auto& pb : env->fan_pool) held += pb.second;
+            if (!env->doomed && env->fan_pool.size() < 4 && held + f->buf_bytes <= ((size_t)64 << 30)) env->fan_pool.emplace_back(f->buf, f->buf_bytes);
+            else (void)hipFree(f->buf);
+        }
+        last = (--env->live_fans == 0) && env->doomed;
     }
     delete f;
+    if (last) env_release(env);   // pgr_env_destroy came first: the environment goes with its last fan
 }
 
 extern "C" int pgr_fan_launch(pgr_env* env, const double* y0, const double* ode_angles_deg, double source_depth,
@@ -1346,6 +1371,10 @@ extern "C" int pgr_fan_launch(pgr_env* env, const double* y0, const double* ode_
     }
     pgr_fan* f = new pgr_fan();
     f->env = env; f->N = N; f->S = S; f->save = (S > 0);
+    {
+        std::lock_guard<std::mutex> lock(env->fan_pool_mutex);
+        env->live_fans++;
+    }
     f->flags = (flags & ~(uint32_t)(PGR_COMPACT | PGR_PACKED_END | PGR_LAUNCH_SLOWNESS)) | PGR_SAMPLE_MAJOR | PGR_SAVE_LINSPACE;
     f->stream = env->stream;
     const size_t ns_bytes = (size_t)N * (size_t)S * sizeof(double);

@@ -906,6 +906,27 @@ def test_device_resident_fan_equals_the_eager_fan(lib):
     assert np.array_equal(c_.rs, d_.rs) and np.array_equal(c_.zs, d_.zs) and np.array_equal(c_.thetas, d_.thetas)
 
 
+def test_environment_closed_before_its_device_resident_fan(lib):
+    """pgr_env_destroy while a device-resident fan of the environment is still in flight: the release is deferred to the
+    fan's own destruction (the fan uses the environment's stream, tables and buffer pool), so the fan still delivers --
+    and equals the fan shot through the host entry."""
+    arrs = munk_arrays(100e3)
+    y0 = y0_for(oracle, arrs, 1000.0, 0.0, -np.linspace(-15, 15, 4096))
+    env = lib.EnvHandle(*arrs)
+    ref = env.shoot_fan(y0, 0.0, 100e3, 51, sample_major=True)
+    for rep in range(3):
+        e2 = lib.EnvHandle(*arrs)
+        fan = lib.FanHandle(e2, 0.0, 100e3, 51, y0=y0)
+        e2.close()                      # kernel possibly still running
+        assert e2._h is None
+        got = fan.fetch_rays()
+        got.update(fan.fetch_samples(compact=False))
+        for name in ("end", "n_bott", "n_surf", "status", "n_steps", "T", "z", "p"):
+            assert np.array_equal(got[name], ref[name], equal_nan=True), (rep, name)
+        fan.close()                     # ... and the environment goes with it
+    env.close()
+
+
 def test_two_device_resident_fans_in_flight_fetched_from_two_threads(lib):
     """Two fans launched back to back on ONE environment (both kernels in flight on its stream, buffers from its pool) and
     fetched concurrently from two host threads -- per-ray arrays, then all three trajectory arrays through the pipelined
