@@ -1,7 +1,7 @@
 """Randomised BIT-PARITY sweep, GPU vs the oracle in its correctly-rounded-libm mode, over the random
 environments and shots of tests/helpers.random_case.  Every ray must agree bit for bit -- status,
 bounce counts, accepted and rejected steps, end state, every sample (SciPy order).
-usage: fuzz_bitparity.py [n_envs | seed,seed,...] [lib.so | -] [flatearth]
+usage: fuzz_bitparity.py [n_envs | seed,seed,... | first:last] [lib.so | -] [flatearth]
 `flatearth`: every environment's depth grid, sound speeds and sea floor go through the reference's flat-earth map first
 (REF/environment.py:121-154, 371-401): smoothly non-uniform zin -> the cubic-index depth look-up (kernel ZM = 5) where the
 grid qualifies, the three-node / bin-table forms where it does not."""
@@ -14,7 +14,8 @@ from helpers import y0_for, random_case
 from pygenray_amd import _lib
 
 arg = sys.argv[1] if len(sys.argv) > 1 else "60"
-seeds = [int(v) for v in arg.split(",") if v] if "," in arg else list(range(int(arg)))
+seeds = ([int(v) for v in arg.split(",") if v] if "," in arg else
+         list(range(*[int(v) for v in arg.split(":")])) if ":" in arg else list(range(int(arg))))
 n_seeds = len(seeds)
 if len(sys.argv) > 2 and sys.argv[2] != "-":
     _lib.LIB_PATH = os.path.abspath(sys.argv[2])
