@@ -373,7 +373,7 @@ class FanHandle:
 
     def __init__(self, env, x0, x1, S, y0=None, ode_angles_deg=None, source_depth=0.0, c_source=1.0, rtol=1e-9,
                  atol=1e-6, terminate_backwards=True, max_steps=1_000_000, stored_sign=False, exact_samples=False,
-                 exact_bisection=False, p0=None):
+                 exact_bisection=False, p0=None, skip_nan=False):
         L = load()
         L.pgr_fan_launch.restype = ctypes.c_int
         L.pgr_fan_launch.argtypes = [_vp, _vp, _vp, ctypes.c_double, ctypes.c_double, _i64, ctypes.c_double, ctypes.c_double,
@@ -399,7 +399,7 @@ class FanHandle:
         self.N, self.S = n, int(S)
         flags = (PGR_TERMINATE_BACKWARDS if terminate_backwards else 0) | (PGR_STORED_SIGN if stored_sign else 0) | \
             (PGR_EXACT_SAMPLES if exact_samples else 0) | (PGR_EXACT_BISECTION if exact_bisection else 0) | \
-            (PGR_LAUNCH_SLOWNESS if p0 is not None else 0)
+            (PGR_LAUNCH_SLOWNESS if p0 is not None else 0) | (PGR_SKIP_NAN_Y0 if skip_nan else 0)
         h = _vp()
         check(L.pgr_fan_launch(env._h, _vptr(y0), _vptr(ode_angles_deg), float(source_depth), float(c_source), n,
                                float(x0), float(x1), self.S, float(rtol), float(atol), flags, int(max_steps),

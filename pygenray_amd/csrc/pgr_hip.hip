@@ -1285,7 +1285,8 @@ __global__ void pgr_y0_kernel(const double* __restrict__ ang_deg, int64_t N, dou
     if (k >= N) return;
     y0[3 * k + 0] = 0.0;
     y0[3 * k + 1] = source_depth;
-    y0[3 * k + 2] = pgr_cr_sin(ang_deg[k] * (M_PI / 180.0)) / c_source;
+    const double a = ang_deg[k];
+    y0[3 * k + 2] = (a != a) ? a : pgr_cr_sin(a * (M_PI / 180.0)) / c_source;   // (a NaN angle stays NaN: a padding ray, PGR_SKIP_NAN_Y0)
 }
 
 __global__ void pgr_y0_from_p0_kernel(const double* __restrict__ p0, int64_t N, double source_depth, double* __restrict__ y0)
@@ -1598,6 +1599,7 @@ struct EigenState {
     int32_t* n_trial;
     double* z_end; double* t_end;
     int32_t* n_active;   // [1] brackets still active after this step
+    int64_t spread;      // bracket k's trial ray is ray k * spread of the trial fan (the rays between are NaN: skipped)
 };
 
 __global__ void pgr_eigen_step(EigenState e, int64_t nbk, int first, int iter_count, int max_iter, double rd,
@@ -1605,16 +1607,17 @@ __global__ void pgr_eigen_step(EigenState e, int64_t nbk, int first, int iter_co
 {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nbk) return;
+    const int64_t r = k * e.spread;   // this bracket's ray in the trial fan
     int st = e.state[k];
     double th = e.theta[k];
     if (first) {
         // REF/eigenrays.py:118-120
         th = e.th1[k] - (e.z1[k] + rd) * (e.th2[k] - e.th1[k]) / (e.z2[k] - e.z1[k]);
     } else if (st == 0) {
-        const double zr = -e.end[3 * k + 1];  // ray.z[-1], stored convention (REF/ray_objects.py:51)
+        const double zr = -e.end[3 * r + 1];  // ray.z[-1], stored convention (REF/ray_objects.py:51)
         e.z_end[k] = zr;
-        e.t_end[k] = e.end[3 * k + 0];
-        if (e.status[k] != PGR_RAY_OK) {
+        e.t_end[k] = e.end[3 * r + 0];
+        if (e.status[r] != PGR_RAY_OK) {
             st = 2;                                                  // REF/eigenrays.py:241-245
         } else if (fabs(zr + rd) < ztol) {
             st = 1;                                                  // :247-250
@@ -1632,13 +1635,13 @@ __global__ void pgr_eigen_step(EigenState e, int64_t nbk, int first, int iter_co
     const double nan = __longlong_as_double(0x7ff8000000000000LL);
     if (st == 0) {
         // shoot_ray(theta): ODE angle = -theta (REF/launch_rays.py:251), y0 = [0, z_s, sin(radians(.)) / c] (:284-285)
-        e.y0[3 * k + 0] = 0.0;
-        e.y0[3 * k + 1] = source_depth;
-        e.y0[3 * k + 2] = pgr_cr_sin((-th) * (M_PI / 180.0)) / c_source;
+        e.y0[3 * r + 0] = 0.0;
+        e.y0[3 * r + 1] = source_depth;
+        e.y0[3 * r + 2] = pgr_cr_sin((-th) * (M_PI / 180.0)) / c_source;
         e.n_trial[k] += 1;
         atomicAdd(e.n_active, 1);
     } else {
-        e.y0[3 * k + 0] = 0.0; e.y0[3 * k + 1] = source_depth; e.y0[3 * k + 2] = nan;
+        e.y0[3 * r + 0] = 0.0; e.y0[3 * r + 1] = source_depth; e.y0[3 * r + 2] = nan;
     }
 }
 
@@ -1659,9 +1662,18 @@ extern "C" int pgr_eigen_refine(pgr_env* env, int64_t nbk, const double* th1, co
     std::lock_guard<std::mutex> lock(env->ws_mutex);
     if (!env->stream) HIPCHK(hipStreamCreateWithFlags(&env->stream, hipStreamNonBlocking));
     hipStream_t st = env->stream;
-    // one device block: 4 bracket arrays, theta, z_end, t_end (doubles), y0[3], end[3], 5 int arrays, the counter
-    const size_t nd = (size_t)nbk;
-    const size_t bytes = nd * 8 * (7 + 3 + 3) + nd * 4 * 6 + 256;
+    // The trial rays of different brackets have nothing in common -- launch angles anywhere in the fan, bounces at
+    // different ranges: 64 of them in one wave make that wave service bounces all the time (a service costs the whole
+    // wave ~22 k cycles whoever bounced) and every trial fan lasts several times its slowest ray.  So the trial fan is
+    // SPREAD: bracket k's ray is ray k * spread, the rays between carry a NaN slowness and are skipped
+    // (PGR_SKIP_NAN_Y0) -- up to 1024 brackets get a wave each (one per SIMD), more share waves 2, 4 ... 64 to a wave.
+    int64_t per_wave = 1;
+    while (per_wave < 64 && (nbk + per_wave - 1) / per_wave > 1024) per_wave *= 2;
+    const int64_t spread = 64 / per_wave;
+    // one device block: 4 bracket arrays, theta, z_end, t_end [nbk] (doubles), y0[3], end[3] [nbk * spread], 3 int arrays
+    // [nbk * spread], 2 [nbk], the counter
+    const size_t nd = (size_t)nbk, nr = (size_t)(nbk * spread);
+    const size_t bytes = nd * 8 * 7 + nr * 8 * 6 + nr * 4 * 3 + nd * 4 * 2 + 256;
     // (the environment's grow-only workspace -- the host-pointer fan entry's, which this call does not use: the
     // many small searches of a receiver-depth loop pay no allocation)
     if (bytes > env->ws_bytes) {
@@ -1673,16 +1685,18 @@ extern "C" int pgr_eigen_refine(pgr_env* env, int64_t nbk, const double* th1, co
     }
     double* d = (double*)env->ws;
     EigenState e{};
+    e.spread = spread;
     e.th1 = d; e.th2 = d + nd; e.z1 = d + 2 * nd; e.z2 = d + 3 * nd; e.theta = d + 4 * nd;
     e.z_end = d + 5 * nd; e.t_end = d + 6 * nd; e.y0 = d + 7 * nd;
-    double* end = d + 10 * nd;
+    double* end = d + 7 * nd + 3 * nr;
     e.end = end;
-    int32_t* ib = (int32_t*)(d + 13 * nd);
+    int32_t* ib = (int32_t*)(d + 7 * nd + 6 * nr);
     int32_t* status = ib; e.status = status;
-    e.state = ib + nd; e.n_trial = ib + 2 * nd;
-    int32_t* nbott = ib + 3 * nd; int32_t* nsurf = ib + 4 * nd;
-    e.n_active = ib + 5 * nd;
+    int32_t* nbott = ib + nr; int32_t* nsurf = ib + 2 * nr;
+    e.state = ib + 3 * nr; e.n_trial = ib + 3 * nr + nd;
+    e.n_active = ib + 3 * nr + 2 * nd;
     HIPCHK(hipMemsetAsync(env->ws, 0, bytes, st));
+    HIPCHK(hipMemsetAsync(e.y0, 0xFF, nr * 24, st));   // every ray of the trial fan starts as "skipped" (an all-ones double is a NaN)
     HIPCHK(hipMemcpyAsync(e.th1, th1, nd * 8, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(e.th2, th2, nd * 8, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(e.z1, z1, nd * 8, hipMemcpyHostToDevice, st));
@@ -1700,7 +1714,7 @@ extern "C" int pgr_eigen_refine(pgr_env* env, int64_t nbk, const double* th1, co
         HIPCHK(hipStreamSynchronize(st));
         if (active == 0) break;
         if (it > max_iter + 2) return fail("pgr_eigen_refine: iteration guard");
-        int rc = pgr_shoot_fan_device(env, e.y0, nbk, source_range, receiver_range, nullptr, 1, rtol, atol,
+        int rc = pgr_shoot_fan_device(env, e.y0, (int64_t)nr, source_range, receiver_range, nullptr, 1, rtol, atol,
                                       (flags & PGR_TERMINATE_BACKWARDS) | PGR_SKIP_NAN_Y0, max_steps, nullptr, nullptr, nullptr,
                                       end, nbott, nsurf, status, nullptr, nullptr, (void*)st);
         if (rc) return rc;

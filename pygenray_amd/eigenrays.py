@@ -55,13 +55,17 @@ def _regula_falsi_batch(z1, z2, th1, th2, receiver_depth, source_depth, source_r
         # the SAME initial state as the trial ray the search accepted -- computed on the device from the angle with the
         # correctly rounded sine, as pgr_eigen_step did -- so the ray returned IS the accepted one
         from .launch_rays import _launch_device_fan
+        # (one ray per wave while they fit one wave per SIMD: the eigenrays of different brackets bounce at different ranges)
+        spread = 64 if len(idx) <= 1024 else 1
         h, r = _launch_device_fan(source_depth, source_range, -th_found[idx], receiver_range, S, environment, rtol,
-                                  terminate_backwards, flatearth, device=device, stored_sign=True, device_y0=True)
+                                  terminate_backwards, flatearth, device=device, stored_sign=True, device_y0=True, spread=spread)
         LAST_SEARCH_STATS["launches"] += 1
-        rays = h.fetch_rays()
-        smp = h.fetch_samples(("T", "z", "p"), compact=False)
+        rays = {k: v[::spread] for k, v in h.fetch_rays().items()}
+        if not np.all(rays["status"] == 0):
+            raise RuntimeError("find_eigenrays: a re-shot eigenray differs from the trial ray the search accepted")
+        smp = h.fetch_samples(("T", "z", "p"), compact=True)      # (the padding rays have status 8: squeezed out on the device)
         h.close()
-        if not np.all(rays["status"] == 0) or not np.all(np.abs(-rays["end"][:, 1] + receiver_depth) < ztol):
+        if not np.all(np.abs(-rays["end"][:, 1] + receiver_depth) < ztol):
             raise RuntimeError("find_eigenrays: a re-shot eigenray differs from the trial ray the search accepted")
         if not np.array_equal(-rays["end"][:, 1], out["z_end"][idx]):
             raise RuntimeError("find_eigenrays: a re-shot eigenray does not end where its trial ray did")

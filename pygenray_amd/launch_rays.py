@@ -98,10 +98,12 @@ def _initial_slowness(ode_angles_deg, c):
 
 def _launch_device_fan(source_depth, source_range, ode_angles_deg, receiver_range, num_range_save, environment, rtol,
                        terminate_backwards, flatearth, device=0, max_steps=1_000_000, stored_sign=True,
-                       device_y0=False):
+                       device_y0=False, spread=1):
     """The fan of _shoot_ode_angles launched device-resident (``_lib.FanHandle``): returns (handle, r) while the kernel
     runs.  ``device_y0``: the initial states are computed on the device from the angles (correctly rounded sine: what
-    the eigenray refinement's trial rays use) instead of uploaded."""
+    the eigenray refinement's trial rays use) instead of uploaded.  ``spread`` (with device_y0): ray k of the caller is
+    ray k * spread of the launch, the rays between are padding that is never integrated (status 8) -- unrelated rays
+    (the eigenrays of different brackets) get a wave each instead of bouncing in each other's way."""
     backwards = receiver_range < source_range
     env, (cin, rin, zin) = _device_env(environment, flatearth, backwards, device)
     x0, x1 = (-source_range, -receiver_range) if backwards else (source_range, receiver_range)
@@ -111,6 +113,10 @@ def _launch_device_fan(source_depth, source_range, ode_angles_deg, receiver_rang
     ang = np.asarray(ode_angles_deg, dtype=float).reshape(-1)
     kw = dict(rtol=rtol, terminate_backwards=terminate_backwards, max_steps=max_steps, stored_sign=stored_sign)
     if device_y0:
+        if spread > 1:
+            padded = np.full(len(ang) * int(spread), np.nan)
+            padded[::int(spread)] = ang
+            ang, kw = padded, dict(kw, skip_nan=True)
         h = _lib.FanHandle(env, x0, x1, num_range_save, ode_angles_deg=ang, source_depth=source_depth, c_source=c, **kw)
     else:
         # NumPy's own sin(radians(.)) / c, as the reference computes it; [0, z_s, p0] is assembled on the device

@@ -128,7 +128,11 @@ class RayFan:
     @property
     def zs_end(self):
         e = self.__dict__.get("_end")
-        return -e[:, 1] if e is not None else self.zs[:, -1]
+        if e is None:
+            return self.zs[:, -1]
+        if self.__dict__.get("_zs_end") is None:      # (what find_eigenrays brackets on, once per receiver depth)
+            self.__dict__["_zs_end"] = -e[:, 1]
+        return self.__dict__["_zs_end"]
 
     @property
     def ps_end(self):

@@ -1308,6 +1308,16 @@ def test_eigen_refine_device_loop_follows_the_reference_loop(lib):
         np.testing.assert_allclose(got["theta"][state == 1], theta[state == 1], rtol=0, atol=1e-10)
         assert np.all(np.abs(got["z_end"][state == 1] + rd) < 1.0)
         assert got["launches"] == ntrial.max()
+        # The trial fan gives every bracket a wave of its own while there is a wave per SIMD for each (<= 1024 brackets);
+        # more brackets share waves 2, 4, ... 64 to a wave: the same brackets 150 and 3 000 times over come out the same
+        # every time, bit for bit, whatever the spread.
+        th1o, th2o, z1o, z2o = th[starts], th[starts + 1], ze[starts], ze[starts + 1]
+        for reps in (150, 3000):
+            big = env.eigen_refine(np.tile(th1o, reps), np.tile(th2o, reps), np.tile(z1o, reps), np.tile(z2o, reps), rd, zs, 0.0, x1, c0,
+                                   ztol=1.0, max_iter=20)
+            assert big["launches"] == got["launches"]
+            for name in ("state", "n_trial", "theta", "z_end", "t_end"):
+                assert np.array_equal(big[name].reshape(reps, n), np.tile(got[name], (reps, 1)), equal_nan=True), (reps, name)
     assert ntrial.max() >= 4
     # nothing to do / bad arguments
     e = env.eigen_refine(np.zeros(0), np.zeros(0), np.zeros(0), np.zeros(0), rd, zs, 0.0, x1, c0)
