@@ -343,6 +343,8 @@ def main(argv=None):
                 sk.bind(("127.0.0.1", 0))
                 os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
             os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        if one_gpu and world > 1 and args.backend == "nccl":
+            args.backend = "gloo"    # RCCL refuses two ranks on one device ("Duplicate GPU detected"): the rehearsal rides gloo
         if args.backend == "nccl":
             dist.init_process_group(args.backend, device_id=torch.device("cuda", dev_index))
         else:
