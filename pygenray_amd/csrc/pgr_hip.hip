@@ -1058,6 +1058,7 @@ struct OrderedPrefault {
     }
     hipStream_t stream = nullptr;       // the copies' stream, once one has been enqueued
     bool stream_used = false;
+    double t0 = 0;                      // (PGR_TRACE)
     ~OrderedPrefault()
     {
         for (auto& t : th) t.join();
@@ -1065,6 +1066,7 @@ struct OrderedPrefault {
         if (stream_used) (void)hipStreamSynchronize(stream);
         for (size_t k = 0; k < jobs.size(); k++)
             if (reg[k].load() == 2) (void)hipHostUnregister(jobs[k].dst);
+        if (t0 != 0) PGR_MARK(t0, "destination buffers unlocked");   // (0.1-0.4 ms for eighteen 128 MB sub-jobs)
     }
 };
 }  // namespace
@@ -1101,6 +1103,7 @@ static int d2h_pipelined(std::vector<D2HJob> jobs, hipStream_t st, int device, R
     }
     OrderedPrefault pf(jobs, device);
     pf.stream = st;
+    if (trace_on()) pf.t0 = t0;
     unsigned nt = std::thread::hardware_concurrency();
     nt = nt < 1 ? 1 : (nt > 16 ? 16 : nt);
     pf.run(nt);
