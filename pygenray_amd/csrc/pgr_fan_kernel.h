@@ -438,6 +438,9 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
         // only taken branch is its own back-edge)
         do {
         trips++;
+#ifdef PGR_DBG_SAMPLE_TRIPS   // experiments: in how many trips does ANY lane of the wave evaluate a sample / how many lanes do
+        bool dbg_ws = false;
+#endif
         PGR_STAMP(0);
         if (RINGK && ring_R > 0) rbase = ring_base[wv];
         if (status == RUNNING && !parked && !need_init) {
@@ -507,6 +510,9 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                 unsigned active = (up & 3u) | ((up | down) & 12u);
                 g = g_new;
                 bool want_samples = save && (jnext < S - 1) && (rnext <= t_new);
+#ifdef PGR_DBG_SAMPLE_TRIPS
+                dbg_ws = want_samples && !active;
+#endif
                 // samples behind the step (rnext < t: the extrapolated ones a segment's first step
                 // owns, Q5, |xi| up to 1e5) amplify rounding by xi^4 and keep SciPy's order
                 const bool scipy_order = exact_samples || (rnext < t);
@@ -575,6 +581,13 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
             }
         }
         PGR_STAMP(19);
+#ifdef PGR_DBG_SAMPLE_TRIPS
+        {
+            const unsigned long long m = ballot64(dbg_ws);
+            const int ln = threadIdx.x & 63;
+            fallbacks += (ln == 2) ? (m != 0) : (ln == 3) ? __popcll(m) : (ln == 4) ? __popcll(ballot64(status == RUNNING && !parked && !need_init)) : 0;
+        }
+#endif
         run = (status == RUNNING);
         // (behind this trip's ring writes: rows below jnext - 1 will not be written by this lane again)
         if (RINGK && ring_R > 0) ring_pub[wv * 64 + lane_id] = run ? jnext : 0x7fffffff;
