@@ -4,7 +4,7 @@ fan (configs[2]): end states, accepted / rejected step counts and bounce counts.
 DEFAULT environment handling (flat-earth transformed tables, non-uniform depth grid -> the cubic-index look-up):
 3 = configs[1]'s tables transformed, 4 = configs[2]'s tables transformed (both 1000 km), 5 = OceanEnvironment2D()
 itself (4500 -> 4900 m slope, 100 km).
-usage: bitparity.py [lib.so|-] [stride] [config 1..5] [exact]"""
+usage: bitparity.py [lib.so|-] [stride] [config 1..5] [exact|-] [angles in the fan, default 100000] [S, default 101]"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -30,9 +30,10 @@ else:
                            coords={"range": r, "depth": z})
         env_obj = pr.OceanEnvironment2D(ssp, pr.DataArray(np.full(len(r), 5000.0), dims=["range"], coords={"range": r}), flat_earth_transform=True)
     arrs = _unpack_envi(env_obj, flatearth=True)
-theta = np.linspace(-20, 20, 100_000)[::stride]
+n_fan = int(sys.argv[5]) if len(sys.argv) > 5 else 100_000
+theta = np.linspace(-20, 20, n_fan)[::stride]
 y0 = y0_for(oracle, arrs, 1000.0, 0.0, -theta)
-S = 101
+S = int(sys.argv[6]) if len(sys.argv) > 6 else 101
 t0 = time.time()
 o = oracle.shoot_fan(*arrs, y0, 0.0, rmax, S, math=oracle.MATH_CR)
 t1 = time.time()
