@@ -194,6 +194,15 @@ int pgr_eigen_refine(pgr_env* env, int64_t nbk, const double* th1, const double*
                      double receiver_range, double c_source, double rtol, double atol, uint32_t flags,
                      int64_t max_steps, double ztol, int32_t max_iter, double* theta, int32_t* state,
                      int32_t* n_trial, double* z_end, double* t_end, int32_t* launches);
+/* The same search with a receiver depth per bracket, receiver_depths[nbk]: find_eigenrays loops over its receiver
+ * depths (REF/eigenrays.py:62) and searches the brackets of each; an iteration of the device loop lasts as long as
+ * its slowest trial ray whatever the number of brackets, so the brackets of ALL receiver depths iterate together --
+ * R depths cost one search instead of R.  Same results, bracket by bracket, as R calls of pgr_eigen_refine. */
+int pgr_eigen_refine_depths(pgr_env* env, int64_t nbk, const double* th1, const double* th2, const double* z1,
+                            const double* z2, const double* receiver_depths, double source_depth, double source_range,
+                            double receiver_range, double c_source, double rtol, double atol, uint32_t flags,
+                            int64_t max_steps, double ztol, int32_t max_iter, double* theta, int32_t* state,
+                            int32_t* n_trial, double* z_end, double* t_end, int32_t* launches);
 
 /* Arrival-time histogram of a fan's surviving rays on the device (BASELINE configs[4]; the
  * reduction behind pygenray's time-front scatter RayFan.plot_time_front, REF/ray_objects.py:157-222;

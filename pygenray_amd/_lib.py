@@ -343,17 +343,20 @@ class EnvHandle:
 
     def eigen_refine(self, th1, th2, z1, z2, receiver_depth, source_depth, source_range, receiver_range, c_source,
                      rtol=1e-9, atol=1e-6, terminate_backwards=True, max_steps=1_000_000, ztol=1.0, max_iter=20):
-        """pgr_eigen_refine: the false-position loop of REF/eigenrays.py:206-268 for all brackets, on the device."""
+        """pgr_eigen_refine_depths: the false-position loop of REF/eigenrays.py:206-268 for all brackets, on the device.
+        `receiver_depth`: one depth for all brackets, or one per bracket (the brackets of several receiver depths
+        searched together)."""
         L = load()
         th1, th2, z1, z2 = (_c(a).reshape(-1) for a in (th1, th2, z1, z2))
         n = len(th1)
+        rd = _c(np.broadcast_to(np.asarray(receiver_depth, dtype=float), (n,)))
         theta = np.full(n, np.nan); zend = np.full(n, np.nan); tend = np.full(n, np.nan)
         state = np.zeros(n, np.int32); ntrial = np.zeros(n, np.int32)
         launches = ctypes.c_int32(0)
-        L.pgr_eigen_refine.restype = ctypes.c_int
-        L.pgr_eigen_refine.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp] + [ctypes.c_double] * 7 + [ctypes.c_uint32, _i64,
-                                       ctypes.c_double, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_int32)]
-        check(L.pgr_eigen_refine(self._h, n, _vptr(th1), _vptr(th2), _vptr(z1), _vptr(z2), float(receiver_depth),
+        L.pgr_eigen_refine_depths.restype = ctypes.c_int
+        L.pgr_eigen_refine_depths.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp, _vp] + [ctypes.c_double] * 6 + [
+            ctypes.c_uint32, _i64, ctypes.c_double, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_int32)]
+        check(L.pgr_eigen_refine_depths(self._h, n, _vptr(th1), _vptr(th2), _vptr(z1), _vptr(z2), _vptr(rd),
                                  float(source_depth), float(source_range), float(receiver_range), float(c_source),
                                  float(rtol), float(atol), PGR_TERMINATE_BACKWARDS if terminate_backwards else 0,
                                  int(max_steps), float(ztol), int(max_iter), _vptr(theta), _vptr(state), _vptr(ntrial),

@@ -1603,13 +1603,15 @@ struct EigenState {
     double* z_end; double* t_end;
     int32_t* n_active;   // [1] brackets still active after this step
     int64_t spread;      // bracket k's trial ray is ray k * spread of the trial fan (the rays between are NaN: skipped)
+    const double* rd;    // [nbk] receiver depth of each bracket (the brackets of several receiver depths search together)
 };
 
-__global__ void pgr_eigen_step(EigenState e, int64_t nbk, int first, int iter_count, int max_iter, double rd,
+__global__ void pgr_eigen_step(EigenState e, int64_t nbk, int first, int iter_count, int max_iter,
                                double ztol, double source_depth, double c_source)
 {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nbk) return;
+    const double rd = e.rd[k];
     const int64_t r = k * e.spread;   // this bracket's ray in the trial fan
     int st = e.state[k];
     double th = e.theta[k];
@@ -1648,17 +1650,38 @@ __global__ void pgr_eigen_step(EigenState e, int64_t nbk, int first, int iter_co
     }
 }
 
+extern "C" int pgr_eigen_refine_depths(pgr_env* env, int64_t nbk, const double* th1, const double* th2, const double* z1,
+                                       const double* z2, const double* receiver_depths, double source_depth, double source_range,
+                                       double receiver_range, double c_source, double rtol, double atol, uint32_t flags,
+                                       int64_t max_steps, double ztol, int32_t max_iter, double* theta, int32_t* state,
+                                       int32_t* n_trial, double* z_end, double* t_end, int32_t* launches);
+
 extern "C" int pgr_eigen_refine(pgr_env* env, int64_t nbk, const double* th1, const double* th2, const double* z1,
                                 const double* z2, double receiver_depth, double source_depth, double source_range,
                                 double receiver_range, double c_source, double rtol, double atol, uint32_t flags,
                                 int64_t max_steps, double ztol, int32_t max_iter, double* theta, int32_t* state,
                                 int32_t* n_trial, double* z_end, double* t_end, int32_t* launches)
 {
+    if (nbk < 0) return fail("pgr_eigen_refine: negative bracket count");
+    const std::vector<double> rd((size_t)nbk, receiver_depth);
+    return pgr_eigen_refine_depths(env, nbk, th1, th2, z1, z2, rd.data(), source_depth, source_range, receiver_range, c_source,
+                                   rtol, atol, flags, max_steps, ztol, max_iter, theta, state, n_trial, z_end, t_end, launches);
+}
+
+// The same search with a receiver depth PER BRACKET: the brackets of all receiver depths of a find_eigenrays call
+// (REF/eigenrays.py:62 loops over them) iterate together -- every iteration of the loop lasts as long as its slowest
+// trial ray whatever the number of brackets, so R receiver depths cost one search instead of R.
+extern "C" int pgr_eigen_refine_depths(pgr_env* env, int64_t nbk, const double* th1, const double* th2, const double* z1,
+                                       const double* z2, const double* receiver_depths, double source_depth, double source_range,
+                                       double receiver_range, double c_source, double rtol, double atol, uint32_t flags,
+                                       int64_t max_steps, double ztol, int32_t max_iter, double* theta, int32_t* state,
+                                       int32_t* n_trial, double* z_end, double* t_end, int32_t* launches)
+{
     if (!env) return fail("pgr_eigen_refine: null env");
     if (nbk < 0) return fail("pgr_eigen_refine: negative bracket count");
     if (launches) *launches = 0;
     if (nbk == 0) return 0;
-    if (!th1 || !th2 || !z1 || !z2 || !theta || !state || !n_trial || !z_end || !t_end)
+    if (!th1 || !th2 || !z1 || !z2 || !receiver_depths || !theta || !state || !n_trial || !z_end || !t_end)
         return fail("pgr_eigen_refine: null argument");
     if (!(c_source > 0) || !(ztol > 0) || max_iter < 0) return fail("pgr_eigen_refine: bad argument");
     HIPCHK(hipSetDevice(env->device));
@@ -1676,7 +1699,7 @@ extern "C" int pgr_eigen_refine(pgr_env* env, int64_t nbk, const double* th1, co
     // one device block: 4 bracket arrays, theta, z_end, t_end [nbk] (doubles), y0[3], end[3] [nbk * spread], 3 int arrays
     // [nbk * spread], 2 [nbk], the counter
     const size_t nd = (size_t)nbk, nr = (size_t)(nbk * spread);
-    const size_t bytes = nd * 8 * 7 + nr * 8 * 6 + nr * 4 * 3 + nd * 4 * 2 + 256;
+    const size_t bytes = nd * 8 * 8 + nr * 8 * 6 + nr * 4 * 3 + nd * 4 * 2 + 256;
     // (the environment's grow-only workspace -- the host-pointer fan entry's, which this call does not use: the
     // many small searches of a receiver-depth loop pay no allocation)
     if (bytes > env->ws_bytes) {
@@ -1690,10 +1713,13 @@ extern "C" int pgr_eigen_refine(pgr_env* env, int64_t nbk, const double* th1, co
     EigenState e{};
     e.spread = spread;
     e.th1 = d; e.th2 = d + nd; e.z1 = d + 2 * nd; e.z2 = d + 3 * nd; e.theta = d + 4 * nd;
-    e.z_end = d + 5 * nd; e.t_end = d + 6 * nd; e.y0 = d + 7 * nd;
-    double* end = d + 7 * nd + 3 * nr;
+    e.z_end = d + 5 * nd; e.t_end = d + 6 * nd;
+    double* d_rd = d + 7 * nd;
+    e.rd = d_rd;
+    e.y0 = d + 8 * nd;
+    double* end = d + 8 * nd + 3 * nr;
     e.end = end;
-    int32_t* ib = (int32_t*)(d + 7 * nd + 6 * nr);
+    int32_t* ib = (int32_t*)(d + 8 * nd + 6 * nr);
     int32_t* status = ib; e.status = status;
     int32_t* nbott = ib + nr; int32_t* nsurf = ib + 2 * nr;
     e.state = ib + 3 * nr; e.n_trial = ib + 3 * nr + nd;
@@ -1704,12 +1730,13 @@ extern "C" int pgr_eigen_refine(pgr_env* env, int64_t nbk, const double* th1, co
     HIPCHK(hipMemcpyAsync(e.th2, th2, nd * 8, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(e.z1, z1, nd * 8, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(e.z2, z2, nd * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_rd, receiver_depths, nd * 8, hipMemcpyHostToDevice, st));
     const dim3 grid((unsigned)((nbk + 127) / 128)), block(128);
     int n_launch = 0;
     for (int it = 0;; it++) {
         // iter_count of the reference when it tests the limit after trial ray number `it`: it - 1
         HIPCHK(hipMemsetAsync(e.n_active, 0, 4, st));
-        hipLaunchKernelGGL(pgr_eigen_step, grid, block, 0, st, e, nbk, it == 0 ? 1 : 0, it - 1, (int)max_iter, receiver_depth,
+        hipLaunchKernelGGL(pgr_eigen_step, grid, block, 0, st, e, nbk, it == 0 ? 1 : 0, it - 1, (int)max_iter,
                            ztol, source_depth, c_source);
         HIPCHK(hipGetLastError());
         int32_t active = 0;

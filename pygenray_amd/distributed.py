@@ -249,6 +249,7 @@ def find_eigenrays_sharded(rays, receiver_depths, source_depth, source_range, re
     from .eigenrays import _find_eigenrays, _regula_falsi_batch
     rank, world = _rank_world(group)
     S = int(num_range_save)
+    together = refine is None     # (the HIP refinement takes a receiver depth per bracket; a stand-in gets one depth per call)
     if refine is None:
         def refine(z1s, z2s, th1s, th2s, receiver_depth):
             return _regula_falsi_batch(z1s, z2s, th1s, th2s, receiver_depth, source_depth, source_range, receiver_range,
@@ -258,7 +259,8 @@ def find_eigenrays_sharded(rays, receiver_depths, source_depth, source_range, re
         nbk = len(z1s)
         mine = np.arange(rank, nbk, world)
         if len(mine):
-            found, th, r, T, Z, P, nb, ns = refine(z1s[mine], z2s[mine], th1s[mine], th2s[mine], receiver_depth)
+            rd_m = np.asarray(receiver_depth)[mine] if np.ndim(receiver_depth) else receiver_depth
+            found, th, r, T, Z, P, nb, ns = refine(z1s[mine], z2s[mine], th1s[mine], th2s[mine], rd_m)
             part = (mine, np.asarray(found), np.asarray(th), np.asarray(r), T[found], Z[found], P[found],
                     np.asarray(nb)[found], np.asarray(ns)[found])
         else:
@@ -281,7 +283,7 @@ def find_eigenrays_sharded(rays, receiver_depths, source_depth, source_range, re
                 r = r_
         return found, th, r, T, Z, P, nb, ns
 
-    return _find_eigenrays(rays, receiver_depths, source_depth, S, environment, refine_dealt)
+    return _find_eigenrays(rays, receiver_depths, source_depth, S, environment, refine_dealt, together=together)
 
 
 def arrival_histogram_sharded(source_depth, source_range, launch_angles, receiver_range, environment, bins, t_min,

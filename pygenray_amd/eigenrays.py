@@ -18,9 +18,10 @@ LAST_SEARCH_STATS = {}
 def _regula_falsi_batch(z1, z2, th1, th2, receiver_depth, source_depth, source_range,
                         receiver_range, num_range_save, environment, ztol, max_iter, kwargs):
     """_find_single_eigenray (REF/eigenrays.py:206-268) for all brackets at once.  The whole
-    false-position loop runs on the device (pgr_eigen_refine: per iteration one small kernel for the
+    false-position loop runs on the device (pgr_eigen_refine_depths: per iteration one small kernel for the
     reference's loop body + the trial rays' initial states, one fan launch over the brackets still
-    active); the eigenrays found are then shot once more with trajectories.
+    active); the eigenrays found are then shot once more with trajectories.  `receiver_depth`: one depth, or one per
+    bracket (the brackets of all receiver depths of a call searched together).
     Returns (found mask, launch angles, r, T, Z, P (stored convention), n_bott, n_surf)."""
     from .launch_rays import _device_env
     from .host_physics import bilinear_interp
@@ -30,19 +31,20 @@ def _regula_falsi_batch(z1, z2, th1, th2, receiver_depth, source_depth, source_r
     device = kwargs.get("device", 0)
     quiet = kwargs.get("quiet", False)   # (not a reference kwarg: suppresses the per-bracket failure message)
     nbk = len(z1)
+    rd_k = np.broadcast_to(np.asarray(receiver_depth, dtype=float), (nbk,))
     S = int(num_range_save)
     backwards = receiver_range < source_range
     env, (cin, rin, zin) = _device_env(environment, flatearth, backwards, device)
     x0, x1 = (-source_range, -receiver_range) if backwards else (source_range, receiver_range)
     c0 = bilinear_interp(x0, source_depth, rin, zin, cin)            # REF/launch_rays.py:284
-    out = env.eigen_refine(th1, th2, z1, z2, receiver_depth, source_depth, x0, x1, c0, rtol=rtol,
+    out = env.eigen_refine(th1, th2, z1, z2, rd_k, source_depth, x0, x1, c0, rtol=rtol,
                            terminate_backwards=terminate_backwards, ztol=ztol, max_iter=max_iter)
     LAST_SEARCH_STATS["launches"] = LAST_SEARCH_STATS.get("launches", 0) + out["launches"]
     LAST_SEARCH_STATS["trial_rays"] = LAST_SEARCH_STATS.get("trial_rays", 0) + int(out["n_trial"].sum())
     if not quiet:
         for q in np.where(out["state"] == 2)[0]:
             # REF/eigenrays.py:241-245
-            print(f"Failed to find eigen ray for receiver depth {receiver_depth} [m] and "
+            print(f"Failed to find eigen ray for receiver depth {rd_k[q]} [m] and "
                   f"approximate launch angle {out['theta'][q]} [m] ray θ = 90°")
     found = out["state"] == 1
     th_found = np.where(found, out["theta"], 0.0)
@@ -65,7 +67,7 @@ def _regula_falsi_batch(z1, z2, th1, th2, receiver_depth, source_depth, source_r
             raise RuntimeError("find_eigenrays: a re-shot eigenray differs from the trial ray the search accepted")
         smp = h.fetch_samples(("T", "z", "p"), compact=True)      # (the padding rays have status 8: squeezed out on the device)
         h.close()
-        if not np.all(np.abs(-rays["end"][:, 1] + receiver_depth) < ztol):
+        if not np.all(np.abs(-rays["end"][:, 1] + rd_k[idx]) < ztol):
             raise RuntimeError("find_eigenrays: a re-shot eigenray differs from the trial ray the search accepted")
         if not np.array_equal(-rays["end"][:, 1], out["z_end"][idx]):
             raise RuntimeError("find_eigenrays: a re-shot eigenray does not end where its trial ray did")
@@ -84,13 +86,26 @@ def _bracket(rays, receiver_depth):
     return starts, z_end[starts], z_end[starts + 1], rays.thetas[starts], rays.thetas[starts + 1]
 
 
-def _find_eigenrays(rays, receiver_depths, source_depth, num_range_save, environment, refine):
+def _find_eigenrays(rays, receiver_depths, source_depth, num_range_save, environment, refine, together=False):
     """The frame of find_eigenrays (REF/eigenrays.py:62-203) around `refine(z1s, z2s, th1s, th2s, receiver_depth)
     -> (found, th, r, T, Z, P, nb, ns)` over ALL brackets of one receiver depth: the single-GPU search refines them in
-    one batch, the sharded one (distributed.find_eigenrays_sharded) deals them to the ranks and gathers."""
+    one batch, the sharded one (distributed.find_eigenrays_sharded) deals them to the ranks and gathers.
+    `together`: the brackets of ALL receiver depths go into ONE call of `refine`, which then gets an array of receiver
+    depths, one per bracket (the device loop's iterations last as long as their slowest trial ray whatever the number
+    of brackets: R receiver depths cost one search instead of R); the results are dealt back depth by depth."""
     erays_dict, num_eigenrays, num_found, failed = {}, {}, {}, {}
+    brackets = [_bracket(rays, receiver_depth) for receiver_depth in receiver_depths]
+    refined = {}
+    if together and sum(len(b[0]) for b in brackets) > 0:
+        cat = [np.concatenate([b[k] for b in brackets]) for k in range(1, 5)]      # z1s, z2s, th1s, th2s
+        rd_k = np.concatenate([np.full(len(b[0]), float(rd)) for b, rd in zip(brackets, receiver_depths)])
+        found, th, r, T, Z, P, nb, ns = refine(cat[0], cat[1], cat[2], cat[3], rd_k)
+        o = 0
+        for rd_idx, b in enumerate(brackets):
+            sl = slice(o, o + len(b[0])); o += len(b[0])
+            refined[rd_idx] = (found[sl], th[sl], r, T[sl], Z[sl], P[sl], nb[sl], ns[sl])
     for rd_idx, receiver_depth in enumerate(receiver_depths):
-        starts, z1s, z2s, th1s, th2s = _bracket(rays, receiver_depth)
+        starts, z1s, z2s, th1s, th2s = brackets[rd_idx]
         num_eigenrays[receiver_depth] = len(starts)
         failed[rd_idx] = []
         if len(starts) == 0:
@@ -100,7 +115,7 @@ def _find_eigenrays(rays, receiver_depths, source_depth, num_range_save, environ
                 np.zeros(0, np.int64), np.zeros(0))
             num_found[rd_idx] = 0
             continue
-        found, th, r, T, Z, P, nb, ns = refine(z1s, z2s, th1s, th2s, receiver_depth)
+        found, th, r, T, Z, P, nb, ns = refined[rd_idx] if rd_idx in refined else refine(z1s, z2s, th1s, th2s, receiver_depth)
         for k in np.where(~found)[0]:
             failed[rd_idx].append((th1s[k], th2s[k]))
         M = int(found.sum())
@@ -120,7 +135,7 @@ def find_eigenrays(rays, receiver_depths, source_depth, source_range, receiver_r
     def refine(z1s, z2s, th1s, th2s, receiver_depth):
         return _regula_falsi_batch(z1s, z2s, th1s, th2s, receiver_depth, source_depth, source_range, receiver_range,
                                    num_range_save, environment, ztol, max_iter, kwargs)
-    return _find_eigenrays(rays, receiver_depths, source_depth, num_range_save, environment, refine)
+    return _find_eigenrays(rays, receiver_depths, source_depth, num_range_save, environment, refine, together=True)
 
 
 __all__ = ["find_eigenrays"]

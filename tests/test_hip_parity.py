@@ -1214,6 +1214,38 @@ def test_config3_eigenray_search_on_the_1e6_angle_fan(lib):
         assert found[0] and abs(th[0] - refc[0]) < 1e-7 and abs(T[0, -1] - refc[1]) < 1e-6 and abs(Z[0, -1] - refc[2]) < 5e-3
 
 
+def test_receiver_depths_searched_together_equal_one_search_each(lib):
+    """find_eigenrays loops over its receiver depths (REF/eigenrays.py:62); here the brackets of ALL depths go through
+    the device loop together (pgr_eigen_refine_depths: a receiver depth per bracket).  The EigenRays of one call with
+    four depths equals, depth by depth and bit for bit, four calls with one depth each -- in as many fan launches as
+    the longest of the four searches alone."""
+    import pygenray_amd as pr
+    from pygenray_amd import eigenrays as er_mod
+    z = np.arange(0, 6000, 1.0)
+    r = np.linspace(0.0, 300e3, 60)
+    env = pr.OceanEnvironment2D(pr.DataArray(np.tile(pr.munk_ssp(z), (60, 1)), dims=["range", "depth"], coords={"range": r, "depth": z}),
+                                pr.DataArray(np.full(60, 5000.0), dims=["range"], coords={"range": r}), flat_earth_transform=False)
+    fan = pr.shoot_rays(1000.0, 0.0, np.linspace(-18, 18, 3001), 300e3, 2, env, debug=False, flatearth=False)
+    depths = [400.0, 1000.0, 1800.0, 3000.0]
+    kw = dict(ztol=1, max_iter=20, debug=False, flatearth=False, quiet=True)
+    er_mod.LAST_SEARCH_STATS.clear()
+    all4 = pr.find_eigenrays(fan, depths, 1000.0, 0.0, 300e3, 51, env, **kw)
+    launches_together = er_mod.LAST_SEARCH_STATS["launches"]
+    launches_alone = []
+    for k, rd in enumerate(depths):
+        er_mod.LAST_SEARCH_STATS.clear()
+        one = pr.find_eigenrays(fan, [rd], 1000.0, 0.0, 300e3, 51, env, **kw)
+        launches_alone.append(er_mod.LAST_SEARCH_STATS.get("launches", 0))
+        assert all4.num_eigenrays[rd] == one.num_eigenrays[rd] and all4.num_eigenrays_found[k] == one.num_eigenrays_found[0]
+        assert all4.failed_eray_theta_brackets[k] == one.failed_eray_theta_brackets[0]
+        assert one.num_eigenrays_found[0] >= 3
+        for name in ("launch_angles", "ts", "zs", "ps", "rs", "n_botts", "n_surfs"):
+            assert np.array_equal(getattr(all4, name)[k], getattr(one, name)[0]), (rd, name)
+        assert np.all(np.abs(all4.zs[k][:, -1] + rd) < 1.0)
+    # (each search: its loop + one re-shoot of the eigenrays found; together: the longest loop + one re-shoot)
+    assert launches_together == max(launches_alone) and sum(launches_alone) > 2 * launches_together
+
+
 def test_config4_end_records_and_arrival_time_histogram_of_1e6_rays(lib):
     """BASELINE configs[4], one GPU's share: 1 000 000 rays, end state only, the kernel writes the
     40-byte end records of the all-gather (PGR_PACKED_END); the 4096-bin arrival-time histogram on the
