@@ -863,8 +863,11 @@ struct Dense {
 #define PGR_AFTER_FIRST_FETCH() do { } while (0)
 #endif
 #define PGR_RK_STAGES(T_, H_)                                                                        \
-    double k20, k21, k22, k30, k31, k32, k40, k41, k42, k50, k51, k52, k60, k61, k62, k70, k71, k72, \
-        cs;                                                                                          \
+    double k30, k31, k32, k40, k41, k42, k50, k51, k52, k60, k61, k62, k70, k71, k72;                \
+    PGR_RK_STAGES_BODY(T_, H_)
+// (the same with K3 ... K7 declared by the caller: the fan kernel keeps them across trips for its parked lanes)
+#define PGR_RK_STAGES_BODY(T_, H_)                                                                   \
+    double k20, k21, k22, cs;                                                                        \
     double wr[5];                                                                                    \
     int ir[5];                                                                                       \
     PGR_STAMP(1);                                                                                    \

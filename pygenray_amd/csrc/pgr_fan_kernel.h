@@ -425,6 +425,18 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
         asm volatile("" : "+v"(C.h_zc_s0));
         asm volatile("" : "+v"(C.h_zc_s2));
     }
+    // K3 ... K7 of a lane's latest attempt live across the trips: a lane that parks takes no further attempt (its lanes of
+    // these registers are not written again), so the service finds the parked step's stage values where the attempt left
+    // them instead of replaying the attempt's six right-hand sides (2.2 k of a service's 21.8 k cycles; the kernel is 1 350
+    // instructions shorter).  Costs no register: the values are live to the end of an attempt anyway, and the early
+    // stages of the next one have room (same VGPR count, same spill count, four v_readlane fewer in the step loop) -- except
+    // in the ZM = 5 trajectory instances, whose look-up coefficients fill the file (12 -> 28 spills): those keep the replay.
+#ifndef PGR_KEEP_K
+#define PGR_KEEP_K (!(ZM == 5 && SAVE != 0))
+#endif
+    constexpr bool KEEPK = PGR_KEEP_K;
+    double k30 = 0, k31 = 0, k32 = 0, k40 = 0, k41 = 0, k42 = 0, k50 = 0, k51 = 0, k52 = 0, k60 = 0, k61 = 0, k62 = 0,
+           k70 = 0, k71 = 0, k72 = 0;
 #undef PGR_AFTER_FIRST_FETCH
 #define PGR_AFTER_FIRST_FETCH() flush_pending()
     // One trip = one step attempt of every stepping lane, THEN the gate that decides whether the
@@ -463,7 +475,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
             h = t_new - t;
             h_abs = fabs(h);
 
-            PGR_RK_STAGES(t, h);
+            PGR_RK_STAGES_BODY(t, h);
             // error estimate, SCIPY/rk.py:106-110,146-147  (E[1] = 0)
             double sc0 = atol + fmax(fabs(y0), fabs(n0)) * rtol;
             double sc1 = atol + fmax(fabs(y1), fabs(n1)) * rtol;
@@ -633,12 +645,17 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                 if (pend && parked) {
                     parked = false;
                     const unsigned active = pk_active;
-                    // replay the parked attempt: same t, y, f and h = t_new - t as when it ran
+                    // the parked attempt: same t, y, f and h = t_new - t as when it ran
                     const double t_new = pk_tnew, h = t_new - t;
-                    PGR_RK_STAGES(t, h);
-                    (void)n0; (void)c_new; (void)es0; (void)es1; (void)es2;
                     Dense D;
-                    PGR_FORM_Q();
+                    if (KEEPK) {
+                        PGR_FORM_Q();          // from the stage values the parked attempt left in this lane's registers
+                    } else {
+                        // replay the parked attempt: same t, y, f and h = t_new - t as when it ran (the names shadow the outer ones)
+                        PGR_RK_STAGES(t, h);
+                        (void)n0; (void)c_new; (void)es0; (void)es1; (void)es2;
+                        PGR_FORM_Q();
+                    }
 #ifdef PGR_DBG_REPLAY
                     dbg_s1 = __builtin_amdgcn_s_memtime();
 #endif

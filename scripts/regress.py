@@ -80,7 +80,10 @@ def run():
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--save"); ap.add_argument("--check")
+    ap.add_argument("--lib", default=None, help="a variant library (scripts/build_variants.py) instead of the product")
     a = ap.parse_args()
+    if a.lib:
+        _lib.LIB_PATH = os.path.abspath(a.lib)
     res = run()
     if a.save:
         json.dump(res, open(a.save, "w"), indent=1); print("saved", a.save)
