@@ -836,7 +836,7 @@ struct Dense {
 // with step H_ -- defines k2*..k7* (k20 = dT/dx, k21 = dz/dx, k22 = dp/dx of stage 2, ...), y_new =
 // (n0, n1, n2) and c_new = c at (T_ + H_, y_new).  Used by the step attempt and, with the same
 // (t, y, f, h), by the service phase of a lane that parked on this step: IEEE arithmetic in a
-// fixed order, so the replay reproduces every bit and nothing has to be kept while parked.
+// fixed order, so a replay reproduces every bit (what the ZM = 5 trajectory instances do; the others keep K3 ... K7).
 #define PGR_SB() __builtin_amdgcn_sched_barrier(0)
 // -DPGR_TIMING (experiments only): s_memtime stamps along one step attempt; the time between stamp
 // k-1 and stamp k accumulates in tacc[k] and comes back in n_rej[] of lanes 0..23 (scripts/phase_times.py)

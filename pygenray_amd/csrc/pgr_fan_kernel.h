@@ -15,8 +15,9 @@
 // Instead a lane that accepted a step with an active event PARKS: it keeps (t, y, f) of the
 // step's start, the step's end and the fired events, and stops stepping until the wave runs a
 // SERVICE phase for all parked lanes together (when `park_lanes` lanes wait, or the oldest has
-// waited `park_trips` trips, or nobody else can step); the service replays the step's stages to
-// get the dense output back.  Per-ray arithmetic is unchanged by when the service runs.
+// waited `park_trips` trips, or nobody else can step); the service forms the step's dense output from
+// the stage values the attempt left in the lane's registers (a parked lane takes no further attempt;
+// the ZM = 5 trajectory instances replay the stages instead).  Per-ray arithmetic is unchanged by when the service runs.
 //
 // Control flow inside a trip is kept free of skipped blocks (a taken skip-branch costs a lone
 // wave ~80 cycles): selects where both sides are cheap, ONE block per kind of rare work, and
@@ -230,8 +231,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     int nb = 0, ns = 0, n_steps = 0, n_rej = 0;
     int jnext = 0;
     double rnext = 0;
-    // a parked lane keeps only the end of its step and which events fired; the service phase
-    // replays the step (PGR_RK_STAGES) to get its dense output back
+    // a parked lane keeps the end of its step, which events fired and -- where they are, in K3 ... K7 -- its stage values
     double pk_tnew = 0;
     unsigned pk_active = 0;
     int waited = 0;
@@ -530,8 +530,8 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                 const bool scipy_order = exact_samples || (rnext < t);
                 Dense D;
                 if (active) {
-                    // park: the step is located, truncated and bounced in the next service phase, which
-                    // replays this attempt's stages from (t, y, f) and pk_tnew -- nothing else is kept
+                    // park: the step is located, truncated and bounced in the next service phase, from (t, y, f),
+                    // pk_tnew and this attempt's stage values (K3 ... K7 stay in this lane's registers: KEEPK)
                     parked = true;
                     pk_active = active;
                     pk_tnew = t_new;
