@@ -279,6 +279,17 @@ def eigenray_leg(env_obj, n_rays):
                "config": "configs[3]: Munk dz=1 m, source (0, 1000 m), receiver (1000 km, 1000 m), "
                          "ztol 1 m, max_iter 20; through pr.shoot_rays + pr.find_eigenrays (device-resident "
                          "false-position loop, pgr_eigen_refine), host buffers included"}
+    # the same fan searched for FOUR receiver depths in one call: their brackets iterate together on the device
+    # (pgr_eigen_refine_depths), so the search costs what its longest single-depth search costs
+    depths = [500.0, 1000.0, 1500.0, 2000.0]
+    er_mod.LAST_SEARCH_STATS.clear()
+    t0 = time.perf_counter()
+    er4 = pr.find_eigenrays(fan, depths, SOURCE_DEPTH, 0.0, RANGE_M, 2, env_obj, ztol=1, max_iter=20,
+                            debug=False, flatearth=False, quiet=True)
+    out["four_receiver_depths"] = {"search_s": time.perf_counter() - t0, "receiver_depths_m": depths,
+                                   "brackets": int(sum(er4.num_eigenrays[d] for d in depths)),
+                                   "found": int(sum(er4.num_eigenrays_found[k] for k in range(len(depths)))),
+                                   "launches": int(er_mod.LAST_SEARCH_STATS.get("launches", 0))}
     return out
 
 
