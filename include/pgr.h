@@ -233,23 +233,11 @@ int pgr_arrival_histogram_device(int device, const double* t_end, int64_t t_stri
  *                            of them wait or the oldest waited `b` step attempts (default 64, 10)
  *   PGR_OPT_PLACEMENT        cost-aware wave scheduling for fans of 1-2 waves per SIMD: a = 2 (default) the
  *                            costliest waves get a SIMD to themselves / are paired with the cheapest, plus
- *                            issue priorities by cost quartile; 1 = priorities only; 0 = strided deal
- *   PGR_OPT_WAVE_RING        (experiment; only in a library built with -DPGR_WAVE_RING=1) kernels whose table lives in
- *                            LDS and that save sample-major trajectories: a = 1 the lanes drop their samples into the
- *                            wave's LDS ring and the wave stores each sample row once, as three 512-byte stores; a = 0
- *                            every lane stores its own samples.  Measured slower; not in the product.
- *   PGR_OPT_SAMPLE_RING      (experiment; only in a library built with -DPGR_SAMPLE_RING=1, an error otherwise)
- *                            kernels whose table lives in HBM / L2 and that save trajectories: a = 1 the
- *                            integrating waves drop their samples into an LDS ring and the workgroup's last
- *                            wave writes complete 512-byte rows; a = 0 every lane stores its own samples.
- *                            b & 255 = ring rows per wave (0 = automatic), b >> 8 = idle sleep of the writer.
- *                            Measured slower than the direct stores; not in the product. */
+ *                            issue priorities by cost quartile; 1 = priorities only; 0 = strided deal */
 #define PGR_OPT_WAVES_PER_BLOCK 0
 #define PGR_OPT_DEPTH_SEARCH 1
 #define PGR_OPT_PARK 2
 #define PGR_OPT_PLACEMENT 3
-#define PGR_OPT_SAMPLE_RING 4
-#define PGR_OPT_WAVE_RING 5
 int pgr_env_set_option(pgr_env* env, int what, int a, int b);
 
 /* Unit-level device entry points (for parity tests of a1-a8, REF/integration_processes.py):

@@ -88,11 +88,6 @@ struct FanArgs {
     int save_formula;  // r_save[j] == j*save_step + x0 bitwise (host verified)
     int park_lanes, park_trips;  // service batching thresholds
     int bathy_lds_off;    // byte offset of the LDS copy of {depth_ranges[nb], depths[nb]}, or -1 (read from HBM)
-    // HBM-table kernels that save trajectories: byte offset of the LDS sample ring and its rows per compute wave
-    // (a power of two; 0 = no ring, samples are stored directly).  With a ring the workgroup's LAST wave is the
-    // writer wave (pgr_fan_kernel.h) and integrates no rays.
-    int ring_lds_off, ring_rows;
-    int ring_sleep;       // the idle writer polls every ring_sleep x 1024 clocks
     const int* wave_map;  // [gridDim.x * waves_per_block] global wave of each slot, -1 = empty; null = strided deal
     int64_t max_steps;
     uint32_t flags;
@@ -858,10 +853,6 @@ struct Dense {
 // do.  An empty asm that takes the sums as operands keeps them in front of the branch.
 #define PGR_KEEP2(a_, b_) do { if (ZM == 5) asm volatile("" : "+v"(a_), "+v"(b_)); } while (0)
 #define PGR_KEEP6(a_, b_, c_, d_, e_, f_) do { if (ZM == 5) asm volatile("" : "+v"(a_), "+v"(b_), "+v"(c_), "+v"(d_), "+v"(e_), "+v"(f_)); } while (0)
-// hook behind the attempt's first table read (the fan kernel's deferred sample stores, HBM-table kernels)
-#ifndef PGR_AFTER_FIRST_FETCH
-#define PGR_AFTER_FIRST_FETCH() do { } while (0)
-#endif
 #define PGR_RK_STAGES(T_, H_)                                                                        \
     double k30, k31, k32, k40, k41, k42, k50, k51, k52, k60, k61, k62, k70, k71, k72;                \
     PGR_RK_STAGES_BODY(T_, H_)
@@ -881,7 +872,6 @@ struct Dense {
     const double zs2 = y1 + (f1 * vA21) * (H_), ps2 = y2 + (f2 * vA21) * (H_);                         \
     PGR_STAMP(3);                                                                                    \
     const auto ft2 = C.fetch(ir[0], zs2);                                                            \
-    PGR_AFTER_FIRST_FETCH();                                                                         \
     PGR_SB();                                                                                        \
     double a31 = f1 * vA31, a32 = f2 * vA31, a41 = f1 * vA41, a42 = f2 * vA41, a51 = f1 * vA51,           \
            a52 = f2 * vA51, a61 = f1 * vA61, a62 = f2 * vA61;                                           \

@@ -54,134 +54,9 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
             lds_bx[env.nb + j] = env.depths[j];
         }
     }
-    // ---- the sample ring (HBM-table kernels that save trajectories) ----
-    // On gfx950 vector loads and stores retire in issue order through ONE counter (vmcnt), so in a kernel whose
-    // table reads are global loads every wait for a table read also waits for the sample stores issued before
-    // it -- and a wave's 64 rays own a given sample row in different trips, so those stores are partial lines,
-    // slow to retire and 2.2x amplified on the way to HBM (profiles/r02_config2_counters.json).  Here the
-    // integrating waves never store a sample to global memory: a lane drops (T, z, p) of sample j into its
-    // wave's LDS ring (row j mod R; ds_write does not count in vmcnt) and publishes its next sample index; the
-    // workgroup's last wave -- the WRITER, which integrates nothing and loads nothing from global memory --
-    // sends row j out as three full 512-byte stores once no lane of that wave can write it any more (every
-    // running lane has published jnext >= j + 2: a lane's later writes, a re-sample after a bounce included,
-    // Q5, have index >= jnext - 1).  A lane that runs more than R rows ahead of its wave's slowest lane stores
-    // that sample directly (its ring entry keeps the sentinel and the writer skips it).
-    // MEASURED (round 3, configs[2] with trajectories, one box): direct stores 7.0 ms; this ring 7.5 ms (16 rows),
-    // 7.7 / 7.9 ms with 8 / 4 rows; the ring with a writer that throws the rows away -- no global store at all
-    // from any wave -- 7.4 ms against 5.9 ms end state only.  The stores are not what the trajectory kernel waits
-    // for, and the ring's bookkeeping plus the writer's share of one SIMD cost more than it saves: it is NOT
-    // compiled into the product (-DPGR_SAMPLE_RING=1 builds it; results are bit-identical either way,
-    // scripts/regress.py).
-#ifndef PGR_SAMPLE_RING
-#define PGR_SAMPLE_RING 0
-#endif
-    constexpr bool RINGK = PGR_SAMPLE_RING && !LDS_TAB && SAVE != 0;
-    // ---- the wave's row ring (LDS-table kernels that save trajectories, sample-major output) ----
-    // A wave's 64 rays own sample row j in different trips, so the lanes' own stores hit each 128-byte line of a row
-    // two or three times, in pieces.  Measured (round 3, `-DPGR_STORE_EXPERIMENT`, headline fan): samples evaluated and
-    // never stored 5.41 ms; stored, every lane to row 0 -- the same store instructions, four full lines each -- 5.45 ms;
-    // stored where they belong 5.76 ms: the pieces cost 0.3 ms, 5 % of the fan.  So the lanes drop (T, z, p) of row j
-    // into the wave's LDS ring (row j mod R, beside the table) and the WAVE stores row j once -- three 512-byte stores,
-    // row address in SGPRs -- when no lane can write it any more: every running lane has jnext >= j + 2 (a lane's later
-    // writes, the re-sample after a bounce included, have index >= jnext - 1).  A lane more than R rows ahead of the
-    // wave's slowest stores that sample itself and leaves the ring entry empty (sentinel).
-    // MEASURED (same round, headline fan, A/B inside one library): ring on 6.22 ms, off 5.82 ms; the lone steepest wave
-    // 5.79 against 5.41 ms -- about 350 cycles per trip for the window test, three ds_write per sample, the
-    // completeness ballot and, on six trips in ten, three ds_read whose latency nothing covers plus the row's
-    // stores: more than the pieces cost.  Bit-identical (scripts/regress.py); NOT compiled into the product
-    // (-DPGR_WAVE_RING=1 builds it, PGR_OPT_WAVE_RING switches it at run time then).
-#ifndef PGR_WAVE_RING
-#define PGR_WAVE_RING 0
-#endif
-    constexpr bool WRING = PGR_WAVE_RING && LDS_TAB && SAVE != 0;
-    const int wv = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
-    const int ring_R = RINGK ? a.ring_rows : 0;
-    const int n_cw = (int)(blockDim.x >> 6) - (ring_R > 0 ? 1 : 0);   // integrating waves of this workgroup
-    // (explicit LDS pointers: a volatile access through a generic pointer is a flat_load / flat_store, which counts
-    // in vmcnt like any global access -- the very coupling the ring is there to remove)
-    const unsigned long long RING_EMPTY = 0x7ff8dead5a5a0001ULL;     // a NaN no arithmetic produces
-    typedef volatile int __attribute__((address_space(3))) * LdsIntP;
-    typedef volatile double __attribute__((address_space(3))) * LdsDblP;
-    typedef __attribute__((address_space(3))) char* LdsCharP;
-    const LdsIntP ring_pub = (LdsIntP)((LdsCharP)(char*)lds_tab + (RINGK ? a.ring_lds_off : 0));  // [n_cw][64] next sample index
-    const LdsIntP ring_base = ring_pub + n_cw * 64;            // [16] first row of each wave still in its ring
-    const LdsIntP ring_done = ring_base + 16;                  // [16] wave's rows all written out
-    const LdsDblP ring_data = (LdsDblP)(ring_base + 64);       // [n_cw][R][3][64]
-    const int wr_R = WRING ? a.ring_rows : 0;                       // rows per wave (a power of two) or 0
-    const LdsDblP wr_all = (LdsDblP)((LdsCharP)(char*)lds_tab + (WRING ? a.ring_lds_off : 0));   // [waves][R][3][64]
-    if (wr_R > 0)
-        for (int k = threadIdx.x; k < (int)(blockDim.x >> 6) * wr_R * 192; k += blockDim.x)
-            wr_all[k] = __longlong_as_double((long long)RING_EMPTY);
-    if (ring_R > 0) {
-        for (int k = threadIdx.x; k < n_cw * 64; k += blockDim.x) ring_pub[k] = 0;
-        for (int k = threadIdx.x; k < 64; k += blockDim.x) ring_base[k] = 0;   // (base and done)
-        for (int k = threadIdx.x; k < n_cw * ring_R * 192; k += blockDim.x)
-            ring_data[k] = __longlong_as_double((long long)RING_EMPTY);
-    }
+    const int wv = threadIdx.x >> 6;
+    const int n_cw = (int)(blockDim.x >> 6);   // waves of this workgroup
     __syncthreads();
-    if (ring_R > 0 && wv == n_cw) {
-        // =========================== WRITER wave ===========================
-        const int S1 = a.S - 1;   // rows 0 .. S-2 pass through the rings; the last column is the exact final state
-        unsigned done_mask = 0;
-        const unsigned all_done = (1u << n_cw) - 1u;
-        __builtin_amdgcn_s_setprio(0);
-        for (int spins = 0; done_mask != all_done && spins < (1 << 24);) {
-            bool progress = false;
-            for (int w = 0; w < n_cw; w++) {
-                if ((done_mask >> w) & 1u) continue;
-                const int pv = ring_pub[w * 64 + lane_id];
-                const int b = __builtin_amdgcn_readfirstlane(ring_base[w]);
-                const bool fin = ballot64(pv != 0x7fffffff) == 0;
-                // rows below `hi` are complete (row r: every lane has published jnext >= r + 2); those of them still
-                // in the ring window go out now, the rest were stored directly by their lanes
-                int hi = b;
-                if (fin) hi = S1;
-                else while (hi < S1 && ballot64(pv < hi + 2) == 0) hi++;
-                if (hi > b) {
-                    int64_t gw = (int64_t)w * gridDim.x + blockIdx.x;
-                    if (a.wave_map) {
-                        const int m = a.wave_map[blockIdx.x * n_cw + w];
-                        gw = (m < 0) ? -1 : (m & 0x0fffffff);
-                    }
-                    const int64_t wray = gw * 64 + lane_id;
-                    const int top = (hi < b + ring_R) ? hi : b + ring_R;
-                    for (int row = b; row < top; row++) {
-                        const LdsDblP e = ring_data + (((w * ring_R + (row & (ring_R - 1))) * 3) * 64 + lane_id);
-                        const double vt = e[0];
-                        if ((unsigned long long)__double_as_longlong(vt) != RING_EMPTY) {
-                            const double vz = e[64], vp = e[128];
-                            const int64_t o = wray * a.stride_ray + (int64_t)row * a.stride_smp;
-#ifdef PGR_RING_EXPERIMENT   // store policy of the writer: 0 streaming, 1 plain (write-back), 2 none at all (wrong results: timing only)
-                            if (((a.ring_sleep >> 8) & 3) == 1) { a.T[o] = vt; a.Z[o] = vz; a.P[o] = vp; }
-                            else if (((a.ring_sleep >> 8) & 3) == 0)
-#endif
-                            {
-                            __builtin_nontemporal_store(vt, a.T + o);
-                            __builtin_nontemporal_store(vz, a.Z + o);
-                            __builtin_nontemporal_store(vp, a.P + o);
-                            }
-                            e[0] = __longlong_as_double((long long)RING_EMPTY);
-                        }
-                    }
-                    ring_base[w] = hi;   // (behind the sentinel writes: the LDS serves one wave's operations in order)
-                    progress = true;
-                }
-                if (fin) {
-                    // this wave's rows are on their way: when they have reached the L2, tell the wave (its epilogue
-                    // overwrites the columns of dropped rays with NaN and must come after them)
-                    __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0) expcnt(0) lgkmcnt(0)
-                    ring_done[w] = 1;
-                    done_mask |= 1u << w;
-                    progress = true;
-                }
-            }
-            if (!progress) {
-                for (int k = 0; k < (a.ring_sleep & 255); k++) __builtin_amdgcn_s_sleep(16);   // 16 x 64 clocks each
-                spins++;
-            }
-        }
-        return;
-    }
     const Ctx<LDS_TAB, ZM> C(env, lds_tab, lds_z, lds_zb, lds_bx);
     C.declare_span(a.x0, a.x1);
     // waves are dealt to workgroups round-robin (wave w of block b = global wave w*grid + b):
@@ -250,92 +125,17 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
 #define Tp (a.T + out_off)
 #define Zp (a.Z + out_off)
 #define Pp (a.P + out_off)
-    // one saved sample (T, z, p) of row j leaves the lane: into the wave's LDS ring when the kernel has one and the
-    // row lies inside its window [rbase, rbase + R) (rbase: the writer's count of rows already sent out, re-read
-    // once per trip; an old value only narrows the window), else straight to global memory -- streaming stores
-    // when the table lives in HBM / L2 (2.4 GB of samples per fan must not evict the table rows), plain ones with
-    // the LDS table (measured faster there)
-    // DEFER (experiment, -DPGR_DEFER_STORES=1; HBM-table kernels that save trajectories): the sample a step produced
-    // is not stored where it is evaluated -- at the end of the attempt, in front of the next attempt's first table
-    // read, whose wait (vmcnt counts loads and stores in issue order) then waits for the three stores as well -- but
-    // held in registers and stored right BEHIND that read, so that the read's wait no longer covers them and they
-    // have a whole stage to retire.  MEASURED (round 3, configs[2], A/B in one gpurun call): 7.18 ms against 7.03 ms
-    // with the stores where they are evaluated -- like the LDS ring above, it removes a wait that is not the
-    // bottleneck and pays for it in registers.  Off.
-#ifndef PGR_DEFER_STORES
-#define PGR_DEFER_STORES 0
-#endif
-    constexpr bool DEFER = PGR_DEFER_STORES && !LDS_TAB && SAVE != 0 && !RINGK;
-    double pd_t = 0, pd_z = 0, pd_p = 0;
-    int pd_j = -1;   // sample index of the pending store, -1 = none
-    auto flush_pending = [&]() __attribute__((always_inline)) {
-        if (DEFER) {
-            if (pd_j >= 0) {
-                const int64_t o = (int64_t)pd_j * a.stride_smp;
-                __builtin_nontemporal_store(pd_t, &Tp[o]);
-                __builtin_nontemporal_store(pd_z, &Zp[o]);
-                __builtin_nontemporal_store(pd_p, &Pp[o]);
-                pd_j = -1;
-            }
-        }
-    };
-#ifdef PGR_STORE_EXPERIMENT
-    long long sink = 0;
-#endif
-    int rbase = 0;
-    int wr_base = 0;                                                 // first row of this wave not yet stored (wave-uniform)
-    const LdsDblP wr_mine = wr_all + (wv * wr_R * 192 + lane_id);     // this lane's column of the wave's ring
-    // the wave stores ring row `row` (a wave-uniform index): lanes whose entry is not the sentinel, then the entries are
-    // emptied.  Row address in scalar registers, the lane's part of it is its ray's offset.
-    auto wr_store_row = [&](int row) __attribute__((always_inline)) {
-        const LdsDblP e = wr_mine + (((row & (wr_R - 1)) * 3) * 64);
-        const double vt = e[0];
-        if ((unsigned long long)__double_as_longlong(vt) != RING_EMPTY) {
-            const double vz = e[64], vp = e[128];
-            const int64_t o = (int64_t)row * a.stride_smp;
-            Tp[o] = vt; Zp[o] = vz; Pp[o] = vp;
-            e[0] = __longlong_as_double((long long)RING_EMPTY);
-        }
-    };
+    // one saved sample (T, z, p) of row j leaves the lane: streaming stores when the table lives in HBM / L2 (2.4 GB
+    // of samples per fan must not evict the table rows), plain ones with the LDS table (measured faster there).
+    // (Built, measured and not kept -- an LDS sample ring with a writer wave, a per-wave row ring, deferred stores:
+    // scripts/experiments/r03_sample_store_experiments.patch.)
     auto emit_sample = [&](int j, double vt, double vz, double vp) __attribute__((always_inline)) {
-        if (DEFER) {
-            flush_pending();   // (a step that owns two samples: the first goes out at once)
-            pd_t = vt; pd_z = vz; pd_p = vp; pd_j = j;
-            return;
-        }
-        bool direct = true;
-        if (WRING) {
-            const bool inr = (unsigned)(j - wr_base) < (unsigned)wr_R;
-            direct = !inr;
-            if (inr) {
-                const LdsDblP e = wr_mine + (((j & (wr_R - 1)) * 3) * 64);
-                e[0] = vt; e[64] = vz; e[128] = vp;
-            }
-        }
-        if (RINGK) {
-            const bool inr = (unsigned)(j - rbase) < (unsigned)ring_R;
-            direct = !inr;
-            if (inr) {
-                const LdsDblP e = ring_data + (((wv * ring_R + (j & (ring_R - 1))) * 3) * 64 + lane_id);
-                e[0] = vt; e[64] = vz; e[128] = vp;
-            }
-        }
-        if (!(RINGK || WRING) || __builtin_expect(ballot64(direct) != 0, 0)) {
-            if (direct) {
-#ifdef PGR_STORE_EXPERIMENT   // timing experiments only (wrong trajectories): 1 = samples evaluated, never stored (folded into a
-                              // value the epilogue stores once); 2 = every sample stored to row 0 (same instructions, no new lines)
-                if (PGR_STORE_EXPERIMENT == 1) { sink ^= __double_as_longlong(vt) ^ __double_as_longlong(vz) ^ __double_as_longlong(vp); return; }
-                const int64_t o = (PGR_STORE_EXPERIMENT == 2) ? 0 : (int64_t)j * a.stride_smp;
-#else
-                const int64_t o = (int64_t)j * a.stride_smp;
-#endif
-                if (LDS_TAB) { Tp[o] = vt; Zp[o] = vz; Pp[o] = vp; }
-                else {
-                    __builtin_nontemporal_store(vt, &Tp[o]);
-                    __builtin_nontemporal_store(vz, &Zp[o]);
-                    __builtin_nontemporal_store(vp, &Pp[o]);
-                }
-            }
+        const int64_t o = (int64_t)j * a.stride_smp;
+        if (LDS_TAB) { Tp[o] = vt; Zp[o] = vz; Pp[o] = vp; }
+        else {
+            __builtin_nontemporal_store(vt, &Tp[o]);
+            __builtin_nontemporal_store(vz, &Zp[o]);
+            __builtin_nontemporal_store(vp, &Pp[o]);
         }
     };
 
@@ -437,8 +237,6 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     constexpr bool KEEPK = PGR_KEEP_K;
     double k30 = 0, k31 = 0, k32 = 0, k40 = 0, k41 = 0, k42 = 0, k50 = 0, k51 = 0, k52 = 0, k60 = 0, k61 = 0, k62 = 0,
            k70 = 0, k71 = 0, k72 = 0;
-#undef PGR_AFTER_FIRST_FETCH
-#define PGR_AFTER_FIRST_FETCH() flush_pending()
     // One trip = one step attempt of every stepping lane, THEN the gate that decides whether the
     // wave services its parked lanes.  (The first trip only runs the gate: every lane starts with
     // need_init.)  The step comes first so that the common path -- nobody parked -- is the loop's
@@ -450,11 +248,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
         // only taken branch is its own back-edge)
         do {
         trips++;
-#ifdef PGR_DBG_SAMPLE_TRIPS   // experiments: in how many trips does ANY lane of the wave evaluate a sample / how many lanes do
-        bool dbg_ws = false;
-#endif
         PGR_STAMP(0);
-        if (RINGK && ring_R > 0) rbase = ring_base[wv];
         if (status == RUNNING && !parked && !need_init) {
             // ---- one attempt of RK45._step_impl, SCIPY/rk.py:111-176 ----
             // min_step = 10 ulp(t) <= 10 * 2^-52 max(|x0|, |x1|) =: min_step_bound for every t of the fan: a wave none
@@ -522,9 +316,6 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                 unsigned active = (up & 3u) | ((up | down) & 12u);
                 g = g_new;
                 bool want_samples = save && (jnext < S - 1) && (rnext <= t_new);
-#ifdef PGR_DBG_SAMPLE_TRIPS
-                dbg_ws = want_samples && !active;
-#endif
                 // samples behind the step (rnext < t: the extrapolated ones a segment's first step
                 // owns, Q5, |xi| up to 1e5) amplify rounding by xi^4 and keep SciPy's order
                 const bool scipy_order = exact_samples || (rnext < t);
@@ -593,25 +384,9 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
             }
         }
         PGR_STAMP(19);
-#ifdef PGR_DBG_SAMPLE_TRIPS
-        {
-            const unsigned long long m = ballot64(dbg_ws);
-            const int ln = threadIdx.x & 63;
-            fallbacks += (ln == 2) ? (m != 0) : (ln == 3) ? __popcll(m) : (ln == 4) ? __popcll(ballot64(status == RUNNING && !parked && !need_init)) : 0;
-        }
-#endif
         run = (status == RUNNING);
-        // (behind this trip's ring writes: rows below jnext - 1 will not be written by this lane again)
-        if (RINGK && ring_R > 0) ring_pub[wv * 64 + lane_id] = run ? jnext : 0x7fffffff;
         pend = run && (parked || need_init);
         pm = ballot64(pend);
-        if (WRING && wr_R > 0) {
-            // row wr_base is complete when every running lane has jnext >= wr_base + 2
-            if (wr_base < S - 1 && ballot64(run && jnext < wr_base + 2) == 0 && ballot64(run) != 0) {
-                wr_store_row(wr_base);
-                wr_base++;
-            }
-        }
         } while (pm == 0 && ballot64(run) != 0);
         // keep ONE exit of the trip loop: without this the compiler threads "left with pm != 0" straight
         // to the gate and gives the loop two exits, whose unification costs the common path two more
@@ -635,13 +410,6 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                 asm volatile("" : "+s"(ks_p));
                 const FanArgs __attribute__((address_space(4))) & as = *(const FanArgs __attribute__((address_space(4))) *)(ks_p + kFanArgsKernargOffset);
                 const double svc_c_lo = es.c_lo, svc_c_hi = es.c_hi;
-                flush_pending();   // (the service may store the same sample index again: keep program order)
-                if (RINGK && ring_R > 0) rbase = ring_base[wv];
-#ifdef PGR_DBG_REPLAY
-                const unsigned long long dbg_s0 = __builtin_amdgcn_s_memtime();
-                unsigned long long dbg_s1 = dbg_s0, dbg_s4 = dbg_s0, dbg_s5 = dbg_s0, dbg_r0 = dbg_s0, dbg_r3 = dbg_s0;
-                unsigned long long dbg_n1 = dbg_s0, dbg_n2 = dbg_s0, dbg_n3 = dbg_s0, dbg_b1 = dbg_s0, dbg_b2 = dbg_s0;
-#endif
                 if (pend && parked) {
                     parked = false;
                     const unsigned active = pk_active;
@@ -656,9 +424,6 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                         (void)n0; (void)c_new; (void)es0; (void)es1; (void)es2;
                         PGR_FORM_Q();
                     }
-#ifdef PGR_DBG_REPLAY
-                    dbg_s1 = __builtin_amdgcn_s_memtime();
-#endif
                     int ev = -1;
                     double best = 0;
                     // (a step that crosses the surface nearly always also crosses the bounding box's
@@ -726,9 +491,6 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                                 sN = sn;
                                 if (it >= 2 && ballot64(ds * h >= 1e-12 * (1.0 + fabs(t))) == 0) break;
                             }
-#ifdef PGR_DBG_REPLAY
-                            dbg_n1 = __builtin_amdgcn_s_memtime();
-#endif
                             const double xs = t + sN * h;
                             // E: rounding noise of F as the event evaluates it.  z(x) = h (Q p) + y_old: half an ulp
                             // of the result for the last add and ~4 roundings of terms <= |h| sum|Q|; the sea floor
@@ -764,15 +526,8 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
         BBOX_ = (z_ > C.h_zhi_tol) | (z_ < C.h_zlo_tol) | ((X_) < es.rlo_tol) | ((X_) > es.rhi_tol);             \
     } while (0)
                             bool ga, gb, bbox_a, bbox_b;
-#ifdef PGR_DBG_REPLAY
-                            asm volatile("" : "+v"(xa), "+v"(xb));
-                            dbg_n2 = __builtin_amdgcn_s_memtime();
-#endif
                             PGR_TRUE_EVENT(xa, ga, bbox_a);
                             PGR_TRUE_EVENT(xb, gb, bbox_b);
-#ifdef PGR_DBG_REPLAY
-                            dbg_n3 = __builtin_amdgcn_s_memtime();
-#endif
                             (void)bbox_a;
                             // with the bounding-box event also active its flip must lie beyond xb, so
                             // that the surface root is the earlier one (SCIPY/ivp.py:100-131)
@@ -809,12 +564,6 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                         const double xtol = 4 * DBL_EPSILON, brtol = 4 * DBL_EPSILON;
                         double cur = t_new, blk = t;
                         bool fcur = true;
-#ifdef PGR_DBG_REPLAY
-                        int n1dbg = 0;
-#endif
-#ifdef PGR_DBG_REPLAY
-                        const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
-#endif
                         {
                             // phase 1: the halvings that can neither end the search nor take brentq's minimum
                             // step (|blk - cur| / 2 stays above 4 delta), kept as (not fired end, fired end): 9
@@ -845,27 +594,14 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                                 lastc = ge | (lastc & !le);
                             }
                             if (n1 > 0) { cur = lastc ? phi : plo; blk = lastc ? plo : phi; fcur = lastc; }
-#ifdef PGR_DBG_REPLAY
-                            n1dbg = n1;
-#endif
                         }
                         // phase 2: brentq's loop as it stands (scipy/optimize/Zeros/brentq.c) for the last few
                         // iterations, all lanes in lock step; the true event is evaluated (for the whole wave,
                         // behind a uniform branch) whenever some lane's iterate lies inside the band, and
                         // decides for those lanes.  A lane whose search has ended (|sbis| < delta) stands still.
-#ifdef PGR_DBG_REPLAY
-                        const unsigned long long dbg_t1 = __builtin_amdgcn_s_memtime();
-                        unsigned long long dbg_ev = 0;
-#endif
-#ifdef PGR_DBG_REPLAY
-                        int dbg_it = 0;
-#endif
                         double fcv = fcur ? 1.0 : 0.0;  // the event at cur, as a number (a carried bool costs more)
                         bool done = !live;
                         for (int it = 0; it < 200; it++) {
-#ifdef PGR_DBG_REPLAY
-                            dbg_it++;
-#endif
                             const double dlt = (xtol + brtol * fabs(cur)) / 2;
                             const double sbis = (blk - cur) / 2;
                             done = !live | (fabs(sbis) < dlt);
@@ -874,30 +610,15 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                             const bool inside = !done & (nw > xa) & (nw < xb);
                             double fnv = (nw >= xb) ? 1.0 : 0.0;
                             if (ballot64(inside) != 0) {
-#ifdef PGR_DBG_REPLAY
-                                const unsigned long long dbg_t2 = __builtin_amdgcn_s_memtime();
-#endif
                                 bool fired, bbox_q;
                                 PGR_TRUE_EVENT(nw, fired, bbox_q);
                                 (void)bbox_q;
                                 fnv = inside ? (fired ? 1.0 : 0.0) : fnv;
-#ifdef PGR_DBG_REPLAY
-                                dbg_ev += __builtin_amdgcn_s_memtime() - dbg_t2;
-#endif
                             }
                             blk = (!done & (fnv != fcv)) ? cur : blk;
                             cur = done ? cur : nw;
                             fcv = done ? fcv : fnv;
                         }
-#ifdef PGR_DBG_REPLAY
-                        (void)dbg_it; (void)n1dbg;
-                        {
-                            const unsigned long long dbg_t3 = __builtin_amdgcn_s_memtime();
-                            const int ln = threadIdx.x & 63;
-                            dbg_r0 = dbg_t0; dbg_r3 = dbg_t3;
-                            fallbacks += (ln == 2) ? (int)(dbg_t1 - dbg_t0) : (ln == 3) ? (int)(dbg_t3 - dbg_t1) : (ln == 4) ? (int)dbg_ev : (ln == 5) ? dbg_it : 0;
-                        }
-#endif
                         if (live && done) { best = cur; ev = bottom ? 1 : 0; }
 #endif
                     }
@@ -934,9 +655,6 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                             if (ev < 0 || xcur < best) { best = xcur; ev = k; }
                         }
                     }
-#ifdef PGR_DBG_REPLAY
-                    dbg_s4 = __builtin_amdgcn_s_memtime();
-#endif
                     if (status == RUNNING) {
                         const double t_end = best;
                         // samples of this (truncated) step, REF/launch_rays.py:763-772 (Q5)
@@ -954,10 +672,6 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                         double r0, r1, r2;
                         D.eval(t, y0, y1, y2, t_end, r0, r1, r2);
                         t = t_end; y0 = r0; y1 = r1; y2 = r2;
-#ifdef PGR_DBG_REPLAY
-                        asm volatile("" : "+v"(y0), "+v"(y1), "+v"(y2));
-                        dbg_b1 = __builtin_amdgcn_s_memtime();
-#endif
                         if (ev == 2) status = PGR_RAY_VERTICAL;
                         else if (ev == 3) status = PGR_RAY_BBOX;
                         else {
@@ -966,10 +680,6 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                             const double pc_b = y2 * c;
                             const PGR_ASIN_DD_T A_b = PGR_ASIN_DD(pc_b);
                             double theta = PGR_ASIN_DD_HI(A_b) * (180.0 / M_PI);  // ray_angle
-#ifdef PGR_DBG_REPLAY
-                            asm volatile("" : "+v"(theta));
-                            dbg_b2 = __builtin_amdgcn_s_memtime();
-#endif
                             double theta_b;
                             if (ev == 0) {
                                 theta_b = -theta;
@@ -1014,9 +724,6 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                         }
                     }
                 }
-#ifdef PGR_DBG_REPLAY
-                dbg_s5 = __builtin_amdgcn_s_memtime();
-#endif
                 if (status == RUNNING && need_init) {
                     // ---- fresh solve_ivp: RK45.__init__ (SCIPY/rk.py:84-104) ----
                     double c;
@@ -1052,38 +759,10 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                         rnext = G.at(jnext);
                     }
                 }
-                if (RINGK && ring_R > 0) ring_pub[wv * 64 + lane_id] = (status == RUNNING) ? jnext : 0x7fffffff;
-#ifdef PGR_DBG_REPLAY
-                {
-                    const unsigned long long dbg_s6 = __builtin_amdgcn_s_memtime();
-                    const int ln = threadIdx.x & 63;
-                    // lanes 6..11: whole service; stage replay + Q; Newton + band edges; (replay: lanes 2-4); samples + root + reflection; init
-                    fallbacks += (ln == 6) ? (int)(dbg_s6 - dbg_s0) : (ln == 7) ? (int)(dbg_s1 - dbg_s0) : (ln == 8) ? (int)(dbg_r0 - dbg_s1)
-                               : (ln == 9) ? (int)(dbg_s4 - dbg_r3) : (ln == 10) ? (int)(dbg_s5 - dbg_s4) : (ln == 11) ? (int)(dbg_s6 - dbg_s5)
-                               : (ln == 12) ? (int)(dbg_n1 - dbg_s1) : (ln == 13) ? (int)(dbg_n2 - dbg_n1) : (ln == 14) ? (int)(dbg_n3 - dbg_n2)
-                               : (ln == 15) ? (int)(dbg_b1 - dbg_s4) : (ln == 16) ? (int)(dbg_b2 - dbg_b1) : (ln == 17) ? (int)(dbg_s5 - dbg_b2) : 0;
-                }
-#endif
             }
         }
     } while (ballot64(status == RUNNING) != 0);
 
-    flush_pending();
-    if (WRING && wr_R > 0) {
-        // every lane is through: the rows still in the ring go out (rows beyond the window were stored by their lanes)
-        const int top = (wr_base + wr_R < S - 1) ? wr_base + wr_R : S - 1;
-        for (int row = wr_base; row < top; row++) wr_store_row(row);
-    }
-#undef PGR_AFTER_FIRST_FETCH
-#define PGR_AFTER_FIRST_FETCH() do { } while (0)
-    if (RINGK && ring_R > 0) {
-        // every lane is through: the writer sends out what is left of this wave's rows.  A wave with a dropped ray
-        // waits for that (its NaN columns below must land after the writer's rows; bounded, never a hang)
-        ring_pub[wv * 64 + lane_id] = 0x7fffffff;
-        if (ballot64(valid && status != PGR_RAY_OK) != 0) {
-            for (int spins = 0; ring_done[wv] == 0 && spins < (1 << 22); spins++) __builtin_amdgcn_s_sleep(8);
-        }
-    }
     if (valid) {
         bool ok = (status == PGR_RAY_OK);
         double nan = __longlong_as_double(0x7ff8000000000000LL);
@@ -1123,9 +802,6 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                 a.end_state[3 * ray + 2] = ok ? y2 : nan;
             }
         }
-#ifdef PGR_STORE_EXPERIMENT
-        if (save && sink == 0x123456789LL) nb++;   // (keeps the folded samples alive)
-#endif
         a.n_bott[ray] = nb;
         a.n_surf[ray] = ns;
         a.status[ray] = status;

@@ -240,9 +240,6 @@ struct pgr_env {
     int depth_search = 0;             // 0: automatic, 1: binary search only, 2: bucket table but no index polynomial (tests)
     int park_lanes = 64, park_trips = 10;
     int place = 2;                    // 0 off, 1 issue priorities only, 2 cost-aware placement + priorities
-    int ring_sleep = 2;
-    int wave_ring = PGR_WAVE_RING;    // (experiment) LDS-table trajectory kernels: samples leave as full rows through the wave's LDS ring
-    int sample_ring = PGR_SAMPLE_RING, ring_rows = 0;  // HBM-table kernels with trajectories: LDS sample ring + writer wave (rows: 0 = automatic)
     hipStream_t stream = nullptr;     // the host-pointer entry's own stream (created on first use)
     EnvDev d{};
     const EnvDev* d_dev = nullptr;  // device copy of `d` (kernel argument by pointer)
@@ -315,9 +312,6 @@ extern "C" const char* pgr_build_info(void)
 #ifdef PGR_LIBM_TRIG
         info += ", device-library asin/sin (NOT bit-identical)";
 #endif
-#if PGR_SAMPLE_RING
-        info += "; LDS sample ring + writer wave in the HBM-table trajectory kernels (experiment)";
-#endif
     });
     return info.c_str();
 }
@@ -349,20 +343,6 @@ extern "C" int pgr_env_set_option(pgr_env* env, int what, int a, int b)
     case PGR_OPT_PLACEMENT:
         if (a < 0 || a > 2) return fail("placement: 0 = off, 1 = priorities only, 2 = placement + priorities");
         env->place = a;
-        return 0;
-    case PGR_OPT_WAVE_RING:
-        if (a < 0 || a > 1) return fail("wave ring: 0 = off, 1 = on");
-        if (a != 0 && !PGR_WAVE_RING) return fail("wave ring: this library was built without it (-DPGR_WAVE_RING=1)");
-        env->wave_ring = a;
-        return 0;
-    case PGR_OPT_SAMPLE_RING:
-        if (a != 0 && !PGR_SAMPLE_RING) return fail("sample ring: this library was built without it (-DPGR_SAMPLE_RING=1)");
-        // (b >> 8: how long the idle writer wave sleeps between two looks at the rings, in units of 1024 clocks; 0 = default)
-        if (a < 0 || a > 1 || !((b & 255) == 0 || (b & 255) == 4 || (b & 255) == 8 || (b & 255) == 16) || (b >> 8) > 1023)
-            return fail("sample ring: a = 0 off / 1 on, b = rows per wave (0 = automatic, 4, 8 or 16) + 256 x idle sleep");
-        env->sample_ring = a;
-        env->ring_rows = b & 255;
-        if (b >> 8) env->ring_sleep = b >> 8;
         return 0;
     default:
         return fail("pgr_env_set_option: unknown option");
@@ -849,7 +829,6 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
     int wpb, threads;
     int64_t blocks;
     size_t lds;
-    bool want_ring = false;
     int place_slot = -1;
     if (lds_tab) {
         // one workgroup per CU (the LDS table is per workgroup): the smallest workgroup that
@@ -866,10 +845,7 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
         if (schedule_waves(env, y0, N, waves, wpb, st, a.wave_map, blocks, place_slot)) return -1;
         lds = tab_bytes + zx_bytes;
     } else {
-        // kernels that save trajectories give the workgroup's last wave slot to the writer of the LDS sample ring
-        // (pgr_fan_kernel.h): 7 integrating waves per workgroup at most
-        want_ring = save && env->sample_ring != 0;
-        const int cap = want_ring ? 7 : 8;
+        const int cap = 8;
         wpb = env->waves_per_block ? env->waves_per_block : 4;
         if (wpb > cap) wpb = cap;
         blocks = (waves + wpb - 1) / wpb;
@@ -889,30 +865,6 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
     {
         const size_t at = (lds + 15) & ~(size_t)15, need = (size_t)D.nb * 16;
         if (at + need <= env->max_lds) { a.bathy_lds_off = (int)at; lds = at + need; }
-    }
-    // the sample ring behind that: per integrating wave 256 B of published sample indices and R rows of
-    // 64 x (T, z, p); one more 256 B block of row counters.  R = the largest of 16, 8, 4 that fits.
-    a.ring_lds_off = 0; a.ring_rows = 0; a.ring_sleep = env->ring_sleep;
-    if (lds_tab && save && (flags & PGR_SAMPLE_MAJOR) && env->wave_ring) {
-        // the wave's row ring of the LDS-table trajectory kernels (pgr_fan_kernel.h): R rows of 64 x (T, z, p) per wave
-        // behind everything else, when that much LDS is left (R = 8 or 4)
-        const size_t at = (lds + 15) & ~(size_t)15;
-        for (int R = 8; R >= 4; R >>= 1) {
-            const size_t need = (size_t)wpb * R * 1536;
-            if (at + need <= env->max_lds) { a.ring_lds_off = (int)at; a.ring_rows = R; lds = at + need; break; }
-        }
-    }
-    if (want_ring) {
-        const size_t at = (lds + 15) & ~(size_t)15;
-        for (int R = 16; R >= 4; R >>= 1) {
-            if (env->ring_rows && R != env->ring_rows) continue;
-            const size_t need = (size_t)wpb * 256 + 256 + (size_t)wpb * R * 1536;
-            if (at + need <= env->max_lds) {
-                a.ring_lds_off = (int)at; a.ring_rows = R; lds = at + need;
-                threads = (wpb + 1) * 64;   // + the writer wave
-                break;
-            }
-        }
     }
 #define PGR_LAUNCH1(LT, ZMV, SV)                                                                     \
     do {                                                                                             \

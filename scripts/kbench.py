@@ -20,8 +20,6 @@ ap.add_argument("--S", type=int, default=1001)
 ap.add_argument("--lib", default=None)
 ap.add_argument("--place", type=int, default=-1)
 ap.add_argument("--park", type=int, nargs="*", default=[64, 10], help="pairs: lanes trips lanes trips ...")
-ap.add_argument("--ring", type=int, nargs=2, default=None, help="sample ring of the HBM-table kernels: on(1)/off(0) rows(0 = automatic)")
-ap.add_argument("--wave-ring", type=int, default=-1, help="row ring of the LDS-table trajectory kernels: 1 on / 0 off")
 ap.add_argument("--exact", action="store_true")
 ap.add_argument("--exact-samples", action="store_true")
 a = ap.parse_args()
@@ -31,10 +29,6 @@ arrs = munk_arrays(a.km * 1e3, nr=(101 if a.slope else 100), sofar_slope=a.slope
 env = _lib.EnvHandle(*arrs)
 if a.place >= 0:
     env.set_option("placement", a.place)
-if a.wave_ring >= 0:
-    env.set_option("wave_ring", a.wave_ring)
-if a.ring is not None:
-    env.set_option("sample_ring", a.ring[0], a.ring[1])
 theta = np.linspace(a.amin, a.amax, a.rays)
 y0 = fan_y0(arrs, 1000.0, 0.0, -theta)
 for mode in a.modes:
