@@ -3,8 +3,11 @@
 fan (configs[2]): end states, accepted / rejected step counts and bounce counts.  Configs 3-5 are the reference's
 DEFAULT environment handling (flat-earth transformed tables, non-uniform depth grid -> the cubic-index look-up):
 3 = configs[1]'s tables transformed, 4 = configs[2]'s tables transformed (both 1000 km), 5 = OceanEnvironment2D()
-itself (4500 -> 4900 m slope, 100 km).
-usage: bitparity.py [lib.so|-] [stride] [config 1..5] [exact|-] [angles in the fan, default 100000] [S, default 101]"""
+itself (4500 -> 4900 m slope, 100 km).  11 / 12 / 13 = the tables bench.py itself builds for its headline line, its
+range_dependent leg and its flatearth_default leg.
+usage: bitparity.py [lib.so|-] [stride] [config 1..5] [exact|-] [angles in the fan, default 100000] [S, default 101] [default-form|-]
+(default-form: also the DEFAULT sample form -- stage-major FMAs inside a step, the SAVE = 1 kernel bench.py times -- against the oracle:
+bit-equal outside a step and in the last column, deviation inside a step reported)"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -19,6 +22,15 @@ exact = len(sys.argv) > 4 and sys.argv[4] == "exact"
 rmax = 1000e3
 if config in (1, 2):
     arrs = munk_arrays(1000e3) if config == 1 else munk_arrays(1000e3, nr=101, sofar_slope=2e-4)
+elif config in (11, 12, 13):
+    # bench.py's OWN tables (bench.munk_tables: the drop-in environment, whose bottom angle is arctan(np.gradient(5000 m)) =
+    # 1e-15 degrees, not 0): 11 = the headline line, 12 = its range_dependent leg, 13 = its flatearth_default leg
+    import bench
+    from pygenray_amd.environment import _unpack_envi
+    env_obj, arrs = bench.munk_tables(1000e3, nr=101, sofar_slope=2e-4) if config == 12 else bench.munk_tables(1000e3)
+    if config == 13:
+        env_obj.flat_earth_transform(lat=35)
+        arrs = _unpack_envi(env_obj, flatearth=True)
 else:
     import pygenray_amd as pr
     from pygenray_amd.environment import _unpack_envi
@@ -58,3 +70,20 @@ for name, m in (("non-bouncing", quiet), ("bouncing", ok & ~quiet), ("all ok", o
     if bad.size:
         print("   first differing rays (index, theta, bounces, n_steps oracle/hip):",
               [(int(k), round(float(theta[k]), 4), int(o["n_bott"][k] + o["n_surf"][k]), int(o["n_steps"][k]), int(g["n_steps"][k])) for k in bad[:6]])
+
+if len(sys.argv) > 7 and sys.argv[7] == "default-form":
+    del g
+    d = env.shoot_fan(y0, 0.0, rmax, S, exact_bisection=exact, sample_major=True)
+    for k in "Tzp":
+        d[k] = d[k].T      # (sample-major [S][N] on the device, as bench.py runs it; compared ray-major)
+    inside = (o["xi"] >= 0) & (o["xi"] <= 1)
+    inside[:, -1] = False
+    okc = ok[:, None]
+    out_eq = all(np.array_equal(d[k][okc & ~inside], o[k][okc & ~inside]) for k in "Tzp")
+    end_eq = np.array_equal(d["end"][ok], np.stack([o["T"][ok, -1], o["z"][ok, -1], o["p"][ok, -1]], 1))
+    cnt_eq = all(np.array_equal(d[k][ok], o[k][ok]) for k in ("n_steps", "n_rej", "n_bott", "n_surf"))
+    m = okc & inside
+    print(f"default sample form (SAVE = 1 kernel, sample-major): end states bit-equal {end_eq}; step / bounce counts equal {cnt_eq}; "
+          f"{int((okc & ~inside).sum())} samples outside a step (Q5, last column) bit-equal {out_eq}; {int(m.sum())} samples inside a step: "
+          f"max rel dev T {np.abs(d['T'] - o['T'])[m].max() / np.nanmax(o['T'][ok]):.1e}  z {np.abs(d['z'] - o['z'])[m].max() / 5000.0:.1e}  "
+          f"p {np.abs(d['p'] - o['p'])[m].max() * 1500.0:.1e}; bit-equal {np.mean((d['z'] == o['z'])[m]):.4f} of them")

@@ -512,11 +512,98 @@ def g10_eigenrays_1000km():
     save("g10_eigenrays_1000km.npz", **out)
 
 
+# --------------------------------------------------------------------------
+# round 4: wider reference-produced pins at the headline range (a fork pool: the stand-in modules are
+# inherited, each ray is one task like the reference's own pool, REF/launch_rays.py:157-164)
+# --------------------------------------------------------------------------
+_POOL_ARRS = {}
+
+
+def _one_ray_with_noise(task):
+    """One reference ray (array level, as _shoot_single_ray_process does) + the end states of its six
+    neighbours at +-1, 2, 3 ulp of p0 (the reference's own self-noise)."""
+    key, source_depth, x0, x1, th, S = task
+    arrs = _POOL_ARRS[key]
+    one = shoot_array_level(arrs, source_depth, x0, x1, np.array([th]), S)
+    p0 = one["y0"][0, 2]
+    ends = [np.array([one["T"][0, -1], one["z"][0, -1], one["p"][0, -1]])]
+    for ulps in (-3, -2, -1, 1, 2, 3):   # (SURVEY section 8c measured the self-noise with +-1 ... 3 ulp on p0)
+        p = p0
+        for _ in range(abs(ulps)):
+            p = np.nextafter(p, np.sign(ulps) * np.inf)
+        sols, fr, _, _ = lr._shoot_ray_array(np.array([0, source_depth, p]), source_depth, x0, x1,
+                                             *arrs, 1e-9, True, False)
+        ends.append(sols[-1].y[:, -1].copy() if fr is not None else np.full(3, np.nan))
+    one["neighbour_ends"] = np.array(ends)[None, :, :]                 # [ray][0, -3, -2, -1, +1, +2, +3 ulp][T, z, p]
+    one["selfnoise_end"] = np.ptp(np.array(ends), axis=0)[None, :]
+    return one
+
+
+def shoot_pool(key, arrs, source_depth, x0, x1, theta, S, procs=7):
+    import multiprocessing as mp
+    _POOL_ARRS[key] = arrs
+    t0 = time.time()
+    with mp.get_context("fork").Pool(procs) as pool:
+        parts = pool.map(_one_ray_with_noise, [(key, source_depth, x0, x1, float(th), S) for th in theta], chunksize=1)
+    out = {k: (parts[0][k] if k == "r" else np.concatenate([q[k] for q in parts])) for k in parts[0]}
+    print(f"  {len(theta)} reference rays (+ 6 neighbours at 1 ... 3 ulp of p0 each) in {time.time() - t0:.0f} s; "
+          f"{int(((out['n_bott'] + out['n_surf']) > 0).sum())} bouncing, {int((out['ok'] == 0).sum())} dropped")
+    return out
+
+
+def g11_munk_1000km_wide():
+    """BASELINE configs[1] tables, 288 launch angles (256 over +-20 degrees + 32 steep ones) at 1000 km (the steep third of
+    the fan bounces), S = 101, step counts and the reference's +-1-ulp self-noise per ray."""
+    z = np.arange(0, 6000, 1.0)
+    env = munk_env(1000e3, 100, z)
+    arrs = env_arrays(env)
+    # (+ 32 more steep angles, off the linspace grid: >= 100 of the 288 rays bounce, up to 64 times)
+    theta = np.concatenate([np.linspace(-20.0, 20.0, 256), -np.linspace(13.37, 19.93, 16), np.linspace(13.61, 19.77, 16)])
+    out = shoot_pool("g11", arrs, 1000.0, 0.0, 1000e3, theta, 101)
+    save("g11_munk_1000km_288.npz", theta_ode=theta, source_depth=1000.0, source_range=0.0,
+         receiver_range=1000e3, c_row=arrs[0][0], cp_row=arrs[1][0], rin=arrs[2], zin=arrs[3],
+         depths=arrs[4], depth_ranges=arrs[5], bottom_angles=arrs[6], **out)
+
+
+def g12_config2_wide():
+    """BASELINE configs[2] (sofar axis drifting 2e-4 m/m, dz = 1 m, 1000 km): 128 launch angles over +-20 degrees.
+    The 9.7 MB tables are rebuilt by the test from the formula (checksums stored)."""
+    z1 = np.arange(0, 6000, 1.0)
+    r1 = np.linspace(0.0, 1000e3, 101)
+    c2 = np.array([munk_ssp(z1, sofar_depth=1300 + 2e-4 * ri) for ri in r1])
+    env2 = DuckEnv(c2, r1, z1, np.full(101, 5000.0), r1)
+    arrs2 = env_arrays(env2)
+    theta2 = np.linspace(-20.0, 20.0, 128)
+    out2 = shoot_pool("g12", arrs2, 1000.0, 0.0, 1000e3, theta2, 101)
+    save("g12_config2_128.npz", theta_ode=theta2, source_depth=1000.0, sofar_slope=2e-4, nr=101, r_max=1000e3,
+         cp_checksum=np.sum(arrs2[1]), c_checksum=np.sum(arrs2[0]), **out2)
+
+
+def g13_default_environment():
+    """The reference's DEFAULT environment, OceanEnvironment2D() (REF/environment.py:62-119): Munk on
+    arange(0, 6000, 1), 100 range columns, the 4500 -> 4900 m slope (Q11), flat-earth transform at lat 35
+    (non-uniform zin), bottom angle from the UNtransformed bathymetry (Q10).  64 angles at 100 km as the
+    constructor builds it, and 32 angles at 1000 km with the same tables on a range axis stretched to 1000 km
+    (the bench's flat-earth leg's range).  Only zin / one profile row / the bathymetry are stored."""
+    z = np.arange(0, 6000, 1)
+    for tag, rmax, theta in (("100km", 100e3, np.linspace(-18.0, 18.0, 64)),
+                             ("1000km", 1000e3, np.sort(np.concatenate([np.linspace(-19.9, 19.5, 24), [-16.3, -14.1, -12.2, -10.4, 11.3, 13.2, 15.7, 18.1]])))):
+        r = np.linspace(0, rmax, 100)
+        env = DuckEnv(np.array([munk_ssp(z)] * 100), r, z, np.linspace(4500, 4900, 100), r, lat=35, flat=True)
+        arrs = env_arrays(env, flatearth=True)
+        assert all(np.array_equal(arrs[0][0], row) for row in arrs[0])
+        out = shoot_pool("g13" + tag, arrs, 1000.0, 0.0, rmax, theta, 101)
+        save(f"g13_default_env_{tag}.npz", theta_ode=theta, source_depth=1000.0, source_range=0.0, receiver_range=rmax,
+             c_row=arrs[0][0], cp_row=arrs[1][0], rin=arrs[2], zin=arrs[3], depths=arrs[4], depth_ranges=arrs[5],
+             bottom_angles=arrs[6], **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     table = dict(g1=g1_fixture_case, g2=g2_munk_100km, g3=g3_munk_1000km, g4=g4_range_dependent,
                  g5=g5_analytic_envs, g6=g6_eigenrays, g7=g7_unit_vectors, g8=g8_timing,
-                 g9=g9_irregular_grids, g10=g10_eigenrays_1000km)
+                 g9=g9_irregular_grids, g10=g10_eigenrays_1000km,
+                 g11=g11_munk_1000km_wide, g12=g12_config2_wide, g13=g13_default_environment)
     for w in which:
         print(w)
         table[w]()

@@ -9,7 +9,7 @@ import pytest
 
 import oracle
 from helpers import (load, env_from, tiled_env, munk, munk_arrays, y0_for, assert_fan_parity,
-                     assert_bit_parity, oracle_selfnoise, random_case, XI_MAX)
+                     assert_bit_parity, oracle_selfnoise, random_case, XI_MAX, NOISE_FACTOR)
 
 pytestmark = pytest.mark.gpu
 
@@ -77,9 +77,10 @@ def golden_check(lib, g, arrs, x0, x1, S, prefix="", label="", abs_floor=None, s
     noise = oracle_selfnoise(oracle, arrs, g[prefix + "y0"], x0, x1, S, **kw)
     for n in noise:
         n["status"] = np.where(n["status"] == 0, 0, -1)
-    assert_fan_parity(test, ref, noise_runs=noise,
-                      scales=(float(arrs[3][-1]), float(np.nanmax(ref["T"])), 1 / 1500.0), label=label,
-                      abs_floor=abs_floor, strict_bouncing=strict_bouncing)
+    worst = assert_fan_parity(test, ref, noise_runs=noise,
+                              scales=(float(arrs[3][-1]), float(np.nanmax(ref["T"])), 1 / 1500.0), label=label,
+                              abs_floor=abs_floor, strict_bouncing=strict_bouncing)
+    print(f"\n{label} HIP vs reference:", {k: v for k, v in worst.items() if "median" not in k})
     env.close()
     return out
 
@@ -109,8 +110,29 @@ def test_golden_munk_1000km(lib):
     out = golden_check(lib, g, tiled_env(g), 0.0, 1000e3, 101, label="g3")
     end = out["end"]
     gend = np.stack([g["T"][:, -1], g["z"][:, -1], g["p"][:, -1]], 1)
-    tol = np.maximum(20 * g["selfnoise_end"], 1e-8 * np.array([670.0, 6000.0, 1 / 1500.0]))
+    tol = np.maximum(NOISE_FACTOR * g["selfnoise_end"], 1e-8 * np.array([670.0, 6000.0, 1 / 1500.0]))
     assert np.all(np.abs(end - gend) <= tol)
+
+
+def test_golden_wide_pins_at_the_headline_range(lib):
+    """Round 4's reference-produced vectors (tests/golden/make_golden.py g11-g13): 288 rays of configs[1], 128 of configs[2],
+    64 + 32 of the reference's default (flat-earth, sloping bottom) environment -- HIP against the reference (rule B at
+    NOISE_FACTOR = 10) and against the oracle bit for bit (rule A)."""
+    from test_oracle_golden import end_state_check
+    g = load("g11_munk_1000km_288.npz")
+    out = golden_check(lib, g, tiled_env(g), 0.0, 1000e3, 101, label="g11 configs[1] x 288")
+    print("g11 end states:", end_state_check(g, out, "g11"))
+    g = load("g12_config2_128.npz")
+    arrs = munk_arrays(float(g["r_max"]), nr=int(g["nr"]), sofar_slope=float(g["sofar_slope"]))
+    out = golden_check(lib, g, arrs, 0.0, 1000e3, 101, label="g12 configs[2] x 128")
+    print("g12 end states:", end_state_check(g, out, "g12"))
+    for tag, x1 in (("100km", 100e3), ("1000km", 1000e3)):
+        g = load(f"g13_default_env_{tag}.npz")
+        e = lib.EnvHandle(*tiled_env(g))
+        assert e.query(5) == 1 and e.lds_path     # the cubic-index kernel (ZM = 5)
+        e.close()
+        out = golden_check(lib, g, tiled_env(g), 0.0, x1, 101, label="g13 default environment " + tag)
+        print(f"g13 {tag} end states:", end_state_check(g, out, "g13 " + tag))
 
 
 def test_golden_range_dependent_and_mirrored(lib):
@@ -597,6 +619,86 @@ def test_full_size_default_flat_earth_environment(lib):
     assert len(fan) == int(keep.sum())
     assert np.array_equal(fan.ts[:, -1], a["end"][keep, 0]) and np.array_equal(-fan.zs[:, -1], a["end"][keep, 1])
     assert np.array_equal(fan.n_botts, a["n_bott"][keep])
+
+
+# ------------------------------------------------------------------ the benchmark AS IT IS BENCHMARKED: S = 1001 at 1000 km
+def _as_benchmarked(lib, arrs, label, every=50, exact_too=True):
+    """bench.py's pass over one workload -- DeviceFan(env, y0, 0, 1000 km, S = 1001, sample-major [S][N] outputs left in
+    HBM, ODE signs, linspace save grid recomputed on the device, default wave placement), 1e5 launch angles -- and every
+    `every`-th ray of it against the oracle (MATH_CR): status / bounces / accepted and rejected steps / end state bit-equal;
+    the default sample form (stage-major FMAs inside a step) within 1e-12 x scale inside a step and BIT-EQUAL on the
+    extrapolated (Q5) samples behind and beyond it and in the exact last column; with PGR_EXACT_SAMPLES every one of
+    the 1001 samples of every compared ray bit-equal.  One sample per km = 0.7 samples per accepted step: most steps own
+    one sample, many two, every bounce re-samples (REF/launch_rays.py:745-784, the idx1 == idx2 skip included)."""
+    import torch
+    from pygenray_amd.device_fan import DeviceFan, fan_y0
+    n, S, x1 = 100_000, 1001, 1000e3
+    theta = np.linspace(-20, 20, n)
+    y0 = fan_y0(arrs, 1000.0, 0.0, -theta)
+    assert np.array_equal(y0, y0_for(oracle, arrs, 1000.0, 0.0, -theta))
+    sub = np.arange(0, n, every)
+    o = oracle.shoot_fan(*arrs, y0[sub], 0.0, x1, S, math=oracle.MATH_CR)
+    env = lib.EnvHandle(*arrs)
+    tsub = torch.from_numpy(sub).cuda()
+    stats = None
+    for exact in ((False, True) if exact_too else (False,)):
+        fan = DeviceFan(env, y0, 0.0, x1, S, save=True, sample_major=True, exact_samples=exact)
+        fan.run()
+        torch.cuda.synchronize()
+        g = {"T": fan.T[:, tsub].T.cpu().numpy(), "z": fan.Z[:, tsub].T.cpu().numpy(), "p": fan.P[:, tsub].T.cpu().numpy(),
+             "end": fan.end[tsub].cpu().numpy()}
+        for k in ("n_bott", "n_surf", "status", "n_steps", "n_rej"):
+            g[k] = getattr(fan, k)[tsub].cpu().numpy()
+        st = assert_bit_parity(g, o, label=f"{label}, S = 1001, every {every}th ray" + (", SciPy sample order" if exact else ", default sample form"),
+                               samples=exact)
+        if not exact:
+            stats = st
+            # what the default form may differ by, measured: samples inside a step against SciPy's order
+            ok = o["status"] == 0
+            inside = (o["xi"] >= 0) & (o["xi"] <= 1)
+            inside[:, -1] = False
+            dz = np.abs(g["z"] - o["z"])[ok][inside[ok]].max() / 5000.0
+            dt = np.abs(g["T"] - o["T"])[ok][inside[ok]].max() / np.nanmax(o["T"][ok])
+            outside = ~inside & ok[:, None]
+            assert np.array_equal(g["z"][outside], o["z"][outside]) and np.array_equal(g["T"][outside], o["T"][outside])
+            stats.update(rel_dz_inside=float(dz), rel_dt_inside=float(dt), q5_samples=int((outside[:, :-1]).sum()),
+                         samples_per_step=float(S * ok.sum() / o["n_steps"][ok].sum()),
+                         bouncing=int(((o["n_bott"] + o["n_surf"]) > 0).sum()), total_steps=int(fan.ray_steps()))
+            assert dz < 1e-12 and dt < 1e-12
+        del fan
+    env.close()
+    print(f"\n{label} as benchmarked: {stats}")
+    return stats
+
+
+def test_config1_as_benchmarked_S1001(lib):
+    """BASELINE configs[1] exactly as bench.py runs it (headline line): pgr_fan_kernel<true, 4, 1>."""
+    import bench       # (bench.py's own table producer: its bottom angle is arctan(np.gradient(5000 m)) = 1e-15 degrees, not 0)
+    st = _as_benchmarked(lib, bench.munk_tables(1000e3)[1], "configs[1]")
+    assert st["n"] >= 1990 and st["bouncing"] > 500 and st["q5_samples"] > 1000 and 0.6 < st["samples_per_step"] < 0.8
+
+
+def test_config2_as_benchmarked_S1001(lib):
+    """BASELINE configs[2] exactly as bench.py's `range_dependent` leg runs it: pgr_fan_kernel<false, 4, 1>."""
+    import bench
+    st = _as_benchmarked(lib, bench.munk_tables(1000e3, nr=101, sofar_slope=2e-4)[1], "configs[2]")
+    assert st["n"] >= 1980 and st["bouncing"] > 500 and st["q5_samples"] > 1000
+
+
+def test_flat_earth_leg_as_benchmarked_S1001(lib):
+    """bench.py's `flatearth_default` leg: the configs[1] tables after OceanEnvironment2D's default flat-earth transform
+    (smoothly non-uniform zin; kernel pgr_fan_kernel<true, 5, 1>, cubic index estimate) at 1000 km."""
+    import bench
+    import pygenray_amd as pr
+    env_obj, _ = bench.munk_tables(1000e3)
+    env_obj.flat_earth_transform(lat=35)
+    arrs = pr._unpack_envi(env_obj, flatearth=True)
+    assert not np.allclose(np.diff(arrs[3]), 1.0, rtol=0, atol=1e-9)
+    e = lib.EnvHandle(*arrs)
+    assert e.query(5) == 1 and e.lds_path
+    e.close()
+    st = _as_benchmarked(lib, arrs, "flat-earth leg")
+    assert st["n"] >= 1980 and st["bouncing"] > 500
 
 
 def test_cubic_index_estimate_qualifies_only_smooth_grids(lib):

@@ -11,7 +11,7 @@ from scipy.optimize import brentq
 
 import oracle
 from oracle import scipy_port
-from helpers import (load, env_from, tiled_env, assert_fan_parity, oracle_selfnoise, XI_MAX)
+from helpers import (load, env_from, tiled_env, assert_fan_parity, oracle_selfnoise, XI_MAX, NOISE_FACTOR, REL_TOL, munk_arrays)
 
 
 def golden_as_ref(g, prefix="", xi=None):
@@ -148,10 +148,10 @@ def test_munk_100km_config0_shape():
 def test_munk_1000km_config1_subset():
     g = load("g3_munk_1000km.npz")
     out, worst = check_against_golden(g, tiled_env(g), 0.0, 1000e3, 101, label="g3")
-    # end states within the reference's recorded +-1 ulp self-noise (x20) or 1e-8 relative
+    # end states within the reference's recorded +-1 ulp self-noise (x10) or 1e-8 relative
     end = np.stack([out["T"][:, -1], out["z"][:, -1], out["p"][:, -1]], 1)
     gend = np.stack([g["T"][:, -1], g["z"][:, -1], g["p"][:, -1]], 1)
-    tol = np.maximum(20 * g["selfnoise_end"], 1e-8 * np.array([670.0, 6000.0, 1 / 1500.0]))
+    tol = np.maximum(NOISE_FACTOR * g["selfnoise_end"], 1e-8 * np.array([670.0, 6000.0, 1 / 1500.0]))
     assert np.all(np.abs(end - gend) <= tol)
     quiet = (g["n_bott"] + g["n_surf"]) == 0
     assert np.abs(end - gend)[quiet][:, 1].max() / 5000 < 1e-8
@@ -229,6 +229,68 @@ def test_linear_gradient_and_flatearth_nonuniform_grid():
     assert_fan_parity(test, ref, noise_runs=noise, scales=(5000.0, 55.0, 1 / 1500.0), label="g5 lin")
     g = load("g5_flatearth.npz")
     check_against_golden(g, env_from(g), 0.0, 100e3, 101, label="g5 flat earth")
+
+
+# ----------------------------------------------------------------------------- round 4: the wide pins at the headline range
+def end_state_check(g, out, label):
+    """End states against the REFERENCE's own +-1-ulp self-noise recorded per ray in the golden file (selfnoise_end):
+    within max(REL_TOL x scale, NOISE_FACTOR x self-noise).  Returns the worst deviation / self-noise ratio among the rays
+    that need the noise rule, and the count of such rays."""
+    ok = g["ok"].astype(bool)
+    end = np.stack([out["T"][:, -1], out["z"][:, -1], out["p"][:, -1]], 1)[ok]
+    gend = np.stack([g["T"][:, -1], g["z"][:, -1], g["p"][:, -1]], 1)[ok]
+    scale = np.array([float(np.nanmax(g["T"][ok])), float(g["zin"][-1]) if "zin" in g.files else 6000.0, 1 / 1500.0])
+    d = np.abs(end - gend)
+    sn = g["selfnoise_end"][ok]
+    needs = d > REL_TOL * scale
+    assert np.all(d <= np.maximum(NOISE_FACTOR * sn, REL_TOL * scale)), \
+        f"{label}: end states beyond {NOISE_FACTOR} x the reference's self-noise: rays {np.where((d > np.maximum(NOISE_FACTOR * sn, REL_TOL * scale)).any(1))[0][:8]}"
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ratio = float(np.nanmax(np.where(needs, d / sn, 0.0))) if needs.any() else 0.0
+    return dict(end_noise_ratio=ratio, end_rays_on_noise_rule=int(needs.any(1).sum()), end_worst_rel=[float(v) for v in (d / scale).max(0)])
+
+
+def test_munk_1000km_288_reference_rays():
+    """g11: BASELINE configs[1] tables, 288 REFERENCE rays to 1000 km (104 bouncing, up to 64 bounces)."""
+    g = load("g11_munk_1000km_288.npz")
+    assert len(g["theta_ode"]) == 288 and ((g["n_bott"] + g["n_surf"]) > 0).sum() >= 100 and g["ok"].all()
+    out, worst = check_against_golden(g, tiled_env(g), 0.0, 1000e3, 101, label="g11")
+    worst.update(end_state_check(g, out, "g11"))
+    print("\ng11 oracle vs reference:", worst)
+    # (8 of the 184 rays that never touch a boundary differ by 1e-4 ... 3e-3 m at 1000 km -- as do the reference's own
+    # +-1 ... 3 ulp neighbours of exactly those rays, selfnoise_end: the rule above prices them; the other 176 meet 1e-8)
+    quiet = (g["n_bott"] + g["n_surf"]) == 0
+    dq = np.abs(out["z"][quiet] - g["z"][quiet]).max(1) / 5000
+    assert (dq < 1e-8).sum() >= 170 and np.all((dq < 1e-8) | (g["selfnoise_end"][quiet, 1] > 1e-5))
+
+
+def test_config2_128_reference_rays():
+    """g12: BASELINE configs[2] (range-dependent tables), 128 REFERENCE rays to 1000 km (one of them dropped by the reference)."""
+    g = load("g12_config2_128.npz")
+    arrs = munk_arrays(float(g["r_max"]), nr=int(g["nr"]), sofar_slope=float(g["sofar_slope"]))
+    assert np.sum(arrs[0]) == pytest.approx(float(g["c_checksum"]), rel=1e-15) and np.sum(arrs[1]) == pytest.approx(float(g["cp_checksum"]), rel=1e-12)
+    assert len(g["theta_ode"]) == 128 and ((g["n_bott"] + g["n_surf"]) > 0).sum() >= 39 and (g["ok"] == 0).sum() == 1
+    out, worst = check_against_golden(g, arrs, 0.0, 1000e3, 101, label="g12")
+    worst.update(end_state_check(g, out, "g12"))
+    print("\ng12 oracle vs reference:", worst)
+
+
+def test_default_environment_reference_rays():
+    """g13: the reference's DEFAULT environment (flat-earth transformed Munk tables, the 4500 -> 4900 m slope, bottom angle
+    from the untransformed bathymetry): 64 REFERENCE rays at 100 km, 32 at 1000 km."""
+    for tag, x1, n in (("100km", 100e3, 64), ("1000km", 1000e3, 32)):
+        g = load(f"g13_default_env_{tag}.npz")
+        assert len(g["theta_ode"]) == n and g["ok"].all()
+        assert not np.allclose(np.diff(g["zin"]), 1.0, rtol=0, atol=1e-9) and g["depths"][0] != g["depths"][-1] and np.any(g["bottom_angles"] != 0)
+        out, worst = check_against_golden(g, tiled_env(g), 0.0, x1, 101, label="g13 " + tag)
+        worst.update(end_state_check(g, out, "g13 " + tag))
+        print(f"\ng13 {tag} oracle vs reference:", worst)
+    # ... and these ARE the tables the drop-in environment builds (host side; no GPU needed)
+    import pygenray_amd as pr
+    arrs = pr._unpack_envi(pr.OceanEnvironment2D(), flatearth=True)
+    g = load("g13_default_env_100km.npz")
+    for a, b in zip(arrs, tiled_env(g)):
+        assert np.array_equal(a, b)
 
 
 # ----------------------------------------------------------------------------- the SciPy port
