@@ -39,6 +39,7 @@ PGR_PACKED_END = 256
 PGR_SAVE_LINSPACE = 8
 PGR_SKIP_NAN_Y0 = 512
 PGR_LAUNCH_SLOWNESS = 1024
+PGR_SAMPLE_BLOCKED = 2048
 
 RAY_STATUS = {0: "ok", 1: "vertical", 2: "bbox", 3: "backward", 4: "step_too_small",
               5: "max_steps", 6: "bottom_angle_range", 7: "event_error", 8: "skipped"}

@@ -91,6 +91,7 @@ struct FanArgs {
     const int* wave_map;  // [gridDim.x * waves_per_block] global wave of each slot, -1 = empty; null = strided deal
     int64_t max_steps;
     uint32_t flags;
+    int blk_lds_off;      // PGR_SAMPLE_BLOCKED: byte offset of the per-lane sample staging area in LDS (768 doubles per wave)
 };
 
 // The fan kernel's service phase and epilogue re-read FanArgs from the kernel-argument segment (so that what only they

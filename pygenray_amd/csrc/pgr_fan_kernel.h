@@ -129,7 +129,33 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     // of samples per fan must not evict the table rows), plain ones with the LDS table (measured faster there).
     // (Built, measured and not kept -- an LDS sample ring with a writer wave, a per-wave row ring, deferred stores:
     // scripts/experiments/r03_sample_store_experiments.patch.)
+    // PGR_SAMPLE_BLOCKED (HBM-table kernels): a lane stages its samples 4b ... 4b + 3 in its own LDS slots (no cross-lane
+    // protocol) and stores them itself when the fourth arrives, as one full 32-byte piece per array into [S/4][N][4].  A
+    // re-sample after a bounce rewrites at most sample jnext - 1 (REF/launch_rays.py:766-772): its slot still holds the
+    // block's other samples (nothing of the next block has been staged yet), so the block is simply stored again.
+#ifndef PGR_BLOCKED_SAMPLES
+#define PGR_BLOCKED_SAMPLES 1
+#endif
+    constexpr bool BLK = PGR_BLOCKED_SAMPLES && !LDS_TAB && SAVE != 0;
+    const bool blocked = BLK && (a.flags & PGR_SAMPLE_BLOCKED) != 0;
+    double* const blk = (double*)((char*)lds_tab + (BLK ? a.blk_lds_off : 0)) + (wv * 768 + (int)(threadIdx.x & 63));   // [slot][T, z, p][lane]
+    auto blk_flush = [&](int jb) __attribute__((always_inline)) {
+        const int64_t o = ((int64_t)jb * a.N + ray) * 4;
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        const d2 t0 = {blk[0], blk[192]}, t1 = {blk[384], blk[576]};
+        const d2 z0 = {blk[64], blk[256]}, z1 = {blk[448], blk[640]};
+        const d2 p0 = {blk[128], blk[320]}, p1 = {blk[512], blk[704]};
+        __builtin_nontemporal_store(t0, (d2*)(a.T + o)); __builtin_nontemporal_store(t1, (d2*)(a.T + o + 2));
+        __builtin_nontemporal_store(z0, (d2*)(a.Z + o)); __builtin_nontemporal_store(z1, (d2*)(a.Z + o + 2));
+        __builtin_nontemporal_store(p0, (d2*)(a.P + o)); __builtin_nontemporal_store(p1, (d2*)(a.P + o + 2));
+    };
     auto emit_sample = [&](int j, double vt, double vz, double vp) __attribute__((always_inline)) {
+        if (BLK && blocked) {
+            double* const e = blk + (j & 3) * 192;
+            e[0] = vt; e[64] = vz; e[128] = vp;
+            if ((j & 3) == 3) blk_flush(j >> 2);
+            return;
+        }
         const int64_t o = (int64_t)j * a.stride_smp;
         if (LDS_TAB) { Tp[o] = vt; Zp[o] = vz; Pp[o] = vp; }
         else {
@@ -774,7 +800,18 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
             (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(kp));
         const FanArgs __attribute__((address_space(4))) & a = *(KArgs)(kp + kFanArgsKernargOffset);  // (shadows the argument)
-        if (save) {
+        if (save && BLK && blocked) {
+            if (ok) {
+                // last column = exact final state (REF/launch_rays.py:775-777): into its slot, and the last block goes out
+                // (slots behind it hold an earlier block's samples: they land in the padding rows S ... 4 ceil(S/4) - 1)
+                double* const e = blk + ((S - 1) & 3) * 192;
+                e[0] = y0; e[64] = SGN(y1); e[128] = SGN(y2);
+                blk_flush((S - 1) >> 2);
+            } else {
+                for (int s4 = 0; s4 < 4; s4++) { blk[s4 * 192] = nan; blk[s4 * 192 + 64] = nan; blk[s4 * 192 + 128] = nan; }
+                for (int jb = 0; jb < (S + 3) / 4; jb++) blk_flush(jb);
+            }
+        } else if (save) {
             if (ok) {
                 // last column = exact final state (REF/launch_rays.py:775-777)
                 Tp[(int64_t)(S - 1) * a.stride_smp] = y0;

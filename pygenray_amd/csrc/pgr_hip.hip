@@ -268,7 +268,8 @@ struct pgr_env {
         void* buf = nullptr;
         size_t bytes = 0;
         hipEvent_t ev = nullptr;
-        bool in_flight = false;
+        bool in_flight = false;   // claimed by a launch ...
+        bool recorded = false;    // ... whose event has been recorded for THIS use (only then may hipEventQuery release it)
     };
     std::vector<PlaceSlot> place_slots;
     std::mutex place_mutex;
@@ -732,7 +733,9 @@ static int schedule_waves(pgr_env* env, const double* y0, int64_t N, int64_t wav
     int pick = -1;
     for (size_t k = 0; k < env->place_slots.size() && pick < 0; k++) {
         pgr_env::PlaceSlot& ps = env->place_slots[k];
-        if (ps.in_flight && hipEventQuery(ps.ev) == hipSuccess) ps.in_flight = false;
+        // (a slot that is claimed but whose event has not been recorded yet -- another host thread between its
+        // schedule_waves and its launch -- still carries the completed record of its previous use: not reclaimable)
+        if (ps.in_flight && ps.recorded && hipEventQuery(ps.ev) == hipSuccess) ps.in_flight = false;
         if (!ps.in_flight) pick = (int)k;
     }
     if (pick < 0) {
@@ -749,7 +752,8 @@ static int schedule_waves(pgr_env* env, const double* y0, int64_t N, int64_t wav
         HIPCHK(hipMalloc(&ps.buf, sz));
         ps.bytes = sz;
     }
-    ps.in_flight = true;   // (the event is recorded by the caller behind the fan kernel: place_release)
+    ps.in_flight = true;   // (the event is recorded by the caller behind the fan kernel: PlaceGuard)
+    ps.recorded = false;
     slot_out = pick;
     char* slot = (char*)ps.buf;
     float* cost = (float*)slot;
@@ -830,6 +834,20 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
     int64_t blocks;
     size_t lds;
     int place_slot = -1;
+    // the claimed placement slot becomes reclaimable when everything queued on `st` so far has run: its event is recorded
+    // behind the fan kernel, or -- on an early error return -- behind the map-building kernels already queued
+    struct PlaceGuard {
+        pgr_env* env; hipStream_t st; int& slot;
+        void release() {
+            if (slot < 0) return;
+            std::lock_guard<std::mutex> lock(env->place_mutex);
+            pgr_env::PlaceSlot& ps = env->place_slots[slot];
+            if (hipEventRecord(ps.ev, st) == hipSuccess) ps.recorded = true;
+            else { (void)hipStreamSynchronize(st); ps.in_flight = false; }
+            slot = -1;
+        }
+        ~PlaceGuard() { release(); }
+    } guard{env, st, place_slot};
     if (lds_tab) {
         // one workgroup per CU (the LDS table is per workgroup): the smallest workgroup that
         // covers the fan in a single round, capped at 8 waves
@@ -866,6 +884,15 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
         const size_t at = (lds + 15) & ~(size_t)15, need = (size_t)D.nb * 16;
         if (at + need <= env->max_lds) { a.bathy_lds_off = (int)at; lds = at + need; }
     }
+    // PGR_SAMPLE_BLOCKED: 6 KB of per-lane sample staging per wave behind everything else
+    a.blk_lds_off = 0;
+    if (flags & PGR_SAMPLE_BLOCKED) {
+        if (!save || !(flags & PGR_SAMPLE_MAJOR)) return fail("pgr_shoot_fan: PGR_SAMPLE_BLOCKED goes with trajectories and PGR_SAMPLE_MAJOR");
+        if (lds_tab) return fail("pgr_shoot_fan: PGR_SAMPLE_BLOCKED is for environments whose tables stay in HBM (this one is on the LDS-table path)");
+        const size_t at = (lds + 15) & ~(size_t)15, need = (size_t)wpb * 6144;
+        if (at + need > env->max_lds) return fail("pgr_shoot_fan: no LDS left for PGR_SAMPLE_BLOCKED");
+        a.blk_lds_off = (int)at; lds = at + need;
+    }
 #define PGR_LAUNCH1(LT, ZMV, SV)                                                                     \
     do {                                                                                             \
         if (lds > 64 * 1024)                                                                         \
@@ -892,12 +919,9 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
 #undef PGR_LAUNCH
 #undef PGR_LAUNCH1
     const hipError_t launch_err = hipGetLastError();
-    if (place_slot >= 0) {
-        // the placement map is this launch's until its fan kernel has run
-        std::lock_guard<std::mutex> lock(env->place_mutex);
-        pgr_env::PlaceSlot& ps = env->place_slots[place_slot];
-        if (launch_err != hipSuccess || hipEventRecord(ps.ev, st) != hipSuccess) ps.in_flight = false;
-    }
+    // (the placement map is this launch's until its fan kernel has run: `guard` records the slot's event on `st` here
+    // and on every error return between the slot's pick and this point)
+    guard.release();
     if (launch_err != hipSuccess) return fail(std::string("fan kernel launch: ") + hipGetErrorString(launch_err));
     return 0;
 }

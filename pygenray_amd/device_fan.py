@@ -18,7 +18,7 @@ class DeviceFan:
     def __init__(self, env_handle, y0, source_range, receiver_range, num_range_save, rtol=1e-9,
                  atol=1e-6, terminate_backwards=True, save=True, sample_major=False,
                  max_steps=1_000_000, exact_bisection=False, exact_samples=False, packed_end=False,
-                 n_pad=None):
+                 n_pad=None, sample_blocked=False):
         self.env = env_handle
         dev = torch.device("cuda", env_handle.device)
         self.dev = dev
@@ -29,14 +29,20 @@ class DeviceFan:
         self.flags = (_lib.PGR_TERMINATE_BACKWARDS if terminate_backwards else 0) | \
             (_lib.PGR_SAMPLE_MAJOR if sample_major else 0) | _lib.PGR_SAVE_LINSPACE | \
             (_lib.PGR_EXACT_BISECTION if exact_bisection else 0) | \
-            (_lib.PGR_EXACT_SAMPLES if exact_samples else 0) | (_lib.PGR_PACKED_END if packed_end else 0)
-        self.save, self.sample_major, self.packed_end = save, sample_major, packed_end
+            (_lib.PGR_EXACT_SAMPLES if exact_samples else 0) | (_lib.PGR_PACKED_END if packed_end else 0) | \
+            (_lib.PGR_SAMPLE_BLOCKED if sample_blocked else 0)
+        if sample_blocked and not (save and sample_major):
+            raise ValueError("sample_blocked goes with save=True, sample_major=True")
+        self.save, self.sample_major, self.packed_end, self.sample_blocked = save, sample_major, packed_end, sample_blocked
         f64 = dict(dtype=torch.float64, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
         self.y0 = torch.from_numpy(y0).to(dev)
         self.r_save = torch.from_numpy(np.linspace(self.x0, self.x1, self.S)).to(dev)
         if save:
             shape = (self.S, self.N) if sample_major else (self.N, self.S)
+            if sample_blocked:
+                # PGR_SAMPLE_BLOCKED (include/pgr.h): [ceil(S/4)][N][4]; `rows(t)` gives the (S, N) view of such a tensor
+                shape = ((self.S + 3) // 4, self.N, 4)
             self.T = torch.empty(shape, **f64)
             self.Z = torch.empty(shape, **f64)
             self.P = torch.empty(shape, **f64)
@@ -60,6 +66,14 @@ class DeviceFan:
         self.nb_buf, self.ns_buf, self.st_buf = self.n_bott, self.n_surf, self.status
         self.nsteps_buf, self.nrej_buf = self.n_steps, self.n_rej
         self.n_pad_min = int(n_pad or 0)
+
+    def rows(self, t):
+        """(S, N) form of a trajectory tensor (sample-major fans): row j = sample j of every ray.  The tensor itself, or --
+        for a sample_blocked fan, whose [ceil(S/4)][N][4] buffer has no 2-D strided view -- an un-blocked COPY
+        (`t.permute(0, 2, 1)` is the (S/4, 4, N) view without a copy)."""
+        if not self.sample_blocked:
+            return t
+        return t.permute(0, 2, 1).flatten(0, 1)[:self.S]
 
     def set_y0(self, y0):
         """New initial states for the same buffers (a fan of the same size or smaller: the per-ray outputs are

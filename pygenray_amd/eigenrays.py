@@ -7,6 +7,8 @@ bracket is refined by false position, re-shooting one trial ray per iteration, u
 brackets to a process pool and re-unpacks the environment for every trial ray; here every
 iteration is ONE fan launch holding the trial rays of all still-active brackets.
 """
+import os
+
 import numpy as np
 
 from .ray_objects import RayFan, EigenRays
@@ -58,7 +60,9 @@ def _regula_falsi_batch(z1, z2, th1, th2, receiver_depth, source_depth, source_r
         # correctly rounded sine, as pgr_eigen_step did -- so the ray returned IS the accepted one
         from .launch_rays import _launch_device_fan
         # (one ray per wave while they fit one wave per SIMD: the eigenrays of different brackets bounce at different ranges)
-        spread = 64 if len(idx) <= 1024 else 1
+        # -- and while the padding stays small: the launch owns 3 * N * S * 8 B of HBM for N = spread * len(idx) rays and
+        # the compact fetch sizes its host buffers alike (1000 eigenrays x S = 1001 would be 1.5 GB of each for 24 MB of data)
+        spread = 64 if (len(idx) <= 1024 and len(idx) * 64 * S * 24 <= 256 * 1024 * 1024) else 1
         h, r = _launch_device_fan(source_depth, source_range, -th_found[idx], receiver_range, S, environment, rtol,
                                   terminate_backwards, flatearth, device=device, stored_sign=True, device_y0=True, spread=spread)
         LAST_SEARCH_STATS["launches"] += 1
@@ -69,7 +73,13 @@ def _regula_falsi_batch(z1, z2, th1, th2, receiver_depth, source_depth, source_r
         h.close()
         if not np.all(np.abs(-rays["end"][:, 1] + rd_k[idx]) < ztol):
             raise RuntimeError("find_eigenrays: a re-shot eigenray differs from the trial ray the search accepted")
-        if not np.array_equal(-rays["end"][:, 1], out["z_end"][idx]):
+        # (the ztol check above is the guard the user relies on.  That the re-shot ray -- trajectory kernel -- ends on the SAME
+        # BITS as the accepted trial ray -- end-state kernel -- is a property of the build that tests assert
+        # (tests/test_hip_parity.py, PGR_EIGEN_STRICT=1); a one-ulp divergence between two kernel instances must not fail
+        # a whole search: the affected brackets are recorded instead)
+        differs = -rays["end"][:, 1] != out["z_end"][idx]
+        LAST_SEARCH_STATS["reshot_differs"] = LAST_SEARCH_STATS.get("reshot_differs", 0) + int(differs.sum())
+        if differs.any() and os.environ.get("PGR_EIGEN_STRICT") == "1":
             raise RuntimeError("find_eigenrays: a re-shot eigenray does not end where its trial ray did")
         T[idx], Z[idx], P[idx] = smp["T"].T, smp["z"].T, smp["p"].T
         nb[idx], ns[idx] = rays["n_bott"], rays["n_surf"]

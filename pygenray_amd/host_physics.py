@@ -41,23 +41,43 @@ def ray_angle(x, y, cin, rin, zin):
     return theta, c
 
 
-_EVAL_ENVS = {}   # (ids + shapes of the tables) -> (EnvHandle, the arrays themselves: their ids stay theirs while we hold them)
+_EVAL_ENVS = {}   # (ids + shapes of the tables) -> (EnvHandle, the arrays themselves, their content fingerprint); FIFO
+
+
+def _fingerprint(arrs):
+    """Content of the tables (crc32 of each array's bytes): the reference's functions are pure functions of their array
+    arguments, so a caller that edits a table in place (cin += dc in a sensitivity loop) must not be served from the
+    tables uploaded before the edit."""
+    import zlib
+    return tuple(zlib.crc32(np.ascontiguousarray(a, dtype=np.float64)) for a in arrs)
 
 
 def _device_eval(x, y, cin, cpin, rin, zin, depths, depth_ranges):
     """pgr_eval_points on the tables given; the uploaded environment is kept for the next scalar query on the same
-    arrays (the reference's event functions are called point by point: one table upload per call otherwise)."""
+    arrays WITH THE SAME CONTENT (the reference's event functions are called point by point: one table upload per call
+    otherwise).  At most 4 environments are held, the oldest goes first; `clear_eval_cache()` drops them all."""
     from ._lib import EnvHandle
     arrs = (cin, cpin, rin, zin, depths, depth_ranges)
     key = tuple((id(a), getattr(a, "shape", None)) for a in arrs)
+    fp = _fingerprint(arrs)
     hit = _EVAL_ENVS.get(key)
+    if hit is not None and hit[2] != fp:      # same arrays, edited in place since the upload
+        hit[0].close()
+        del _EVAL_ENVS[key]
+        hit = None
     if hit is None:
         if len(_EVAL_ENVS) >= 4:
-            _, (old_env, _) = _EVAL_ENVS.popitem()
-            old_env.close()
+            oldest = next(iter(_EVAL_ENVS))    # dicts keep insertion order: FIFO
+            _EVAL_ENVS.pop(oldest)[0].close()
         nb = len(depths)
-        hit = _EVAL_ENVS[key] = (EnvHandle(cin, cpin, rin, zin, depths, depth_ranges, np.zeros(nb)), arrs)
+        hit = _EVAL_ENVS[key] = (EnvHandle(cin, cpin, rin, zin, depths, depth_ranges, np.zeros(nb)), arrs, fp)
     return hit[0].eval_points(np.atleast_1d(np.asarray(x, float)), np.asarray(y, float).reshape(-1, 3))
+
+
+def clear_eval_cache():
+    """Release the device environments kept for derivsrd / the event functions."""
+    while _EVAL_ENVS:
+        _EVAL_ENVS.popitem()[1][0].close()
 
 
 def derivsrd(x, y, cin, cpin, rin, zin, depths, depth_ranges):

@@ -119,6 +119,38 @@ class RayFan:
         """True while some trajectory array has not been fetched from the GPU yet."""
         return self.__dict__.get("_dev") is not None
 
+    # A device-resident fan pins 3 * N * S * 8 B of HBM (2.4 GB for 1e5 rays x 1001 samples) until ts, zs AND ps have been
+    # read, or to_host() / release() is called, or the fan is garbage collected; `rs` of such a fan is a read-only broadcast
+    # view of the save grid (np.array(fan.rs) for a private copy).
+    def to_host(self):
+        """Fetch whatever is still on the GPU and give the HBM back; the fan is a plain host object afterwards."""
+        if self.device_resident:
+            self.ts, self.zs, self.ps       # noqa: B018  (the third read closes the handle)
+        return self
+
+    def release(self):
+        """Give the HBM back WITHOUT fetching: trajectory arrays not read so far are gone (reading them raises
+        AttributeError); end states, bounce counts and launch angles stay."""
+        dev = self.__dict__.get("_dev")
+        if dev is not None:
+            dev.close()
+            self.__dict__["_dev"] = None
+
+    def __getstate__(self):
+        """pickle / copy.deepcopy / multiprocessing: the state of a plain host fan (the reference's RayFan is a plain
+        object).  A device-resident fan is fetched first -- its handle wraps a device pointer that means nothing in
+        another process."""
+        self.to_host()
+        d = dict(self.__dict__)
+        d.pop("_dev", None)
+        if d.get("_r") is not None:
+            d.pop("_rs", None)              # the broadcast view is rebuilt from the save grid on first access
+        return d
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self.__dict__.setdefault("_ray_ids", None)
+
     # the state at receiver_range, stored convention, without touching the trajectories
     @property
     def ts_end(self):

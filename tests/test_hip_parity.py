@@ -1008,6 +1008,49 @@ def test_device_resident_fan_equals_the_eager_fan(lib):
     assert np.array_equal(c_.rs, d_.rs) and np.array_equal(c_.zs, d_.zs) and np.array_equal(c_.thetas, d_.thetas)
 
 
+def test_device_resident_fan_pickles_and_releases(lib):
+    """a device-resident RayFan (what pr.shoot_rays returns for large fans) holds a ctypes device pointer --
+    pickle / copy.deepcopy fetch it first and give a plain host fan; to_host() does the same in place; release() gives the
+    HBM back without fetching (unread arrays are gone, end states stay)."""
+    import copy
+    import pickle
+    import pygenray_amd as pr
+    z = np.arange(0, 6000, 1.0); r = np.linspace(0, 100e3, 100)
+    env = pr.OceanEnvironment2D(pr.DataArray(np.tile(pr.munk_ssp(z), (100, 1)), dims=["range", "depth"], coords={"range": r, "depth": z}),
+                                pr.DataArray(np.full(100, 5000.0), dims=["range"], coords={"range": r}), flat_earth_transform=False)
+    theta = np.linspace(-20, 20, 400)
+    eager = pr.shoot_rays(1000.0, 0.0, theta, 100e3, 31, env, debug=False, flatearth=False, device_resident=False)
+    fan = pr.shoot_rays(1000.0, 0.0, theta, 100e3, 31, env, debug=False, flatearth=False, device_resident=True)
+    assert fan.device_resident
+    _ = fan.zs                                     # one of the three read: still resident
+    assert fan.device_resident
+    b = pickle.loads(pickle.dumps(fan))
+    assert not fan.device_resident and not b.device_resident     # the pickle fetched the rest and closed the handle
+    c = copy.deepcopy(pr.shoot_rays(1000.0, 0.0, theta, 100e3, 31, env, debug=False, flatearth=False, device_resident=True))
+    for x in (b, c, fan):
+        for k in ("thetas", "rs", "ts", "zs", "ps", "n_botts", "n_surfs", "source_depths", "ray_ids"):
+            assert np.array_equal(getattr(x, k), getattr(eager, k)), k
+    d = pr.shoot_rays(1000.0, 0.0, theta, 100e3, 31, env, debug=False, flatearth=False, device_resident=True)
+    assert d.to_host() is d and not d.device_resident and np.array_equal(d.ps, eager.ps)
+    e = pr.shoot_rays(1000.0, 0.0, theta, 100e3, 31, env, debug=False, flatearth=False, device_resident=True)
+    zs = e.zs
+    e.release()
+    assert not e.device_resident and np.array_equal(zs, eager.zs) and np.array_equal(e.zs_end, eager.zs[:, -1])
+    with pytest.raises(AttributeError):
+        e.ts
+    # ... and the reference's pure functions are not served from tables uploaded before an in-place edit (ADVICE r3)
+    arrs = [np.array(a) for a in pr._unpack_envi(env, flatearth=False)]
+    y = np.array([0.0, 1000.0, 1e-4])
+    d0 = pr.derivsrd(10e3, y, *arrs[:6])
+    arrs[0] += 1.0                                  # same array objects, new content
+    d1 = pr.derivsrd(10e3, y, *arrs[:6])
+    fresh = [a.copy() for a in arrs]
+    d2 = pr.derivsrd(10e3, y, *fresh[:6])
+    assert not np.array_equal(d0, d1) and np.array_equal(d1, d2)
+    from pygenray_amd import host_physics
+    host_physics.clear_eval_cache()
+
+
 def test_environment_closed_before_its_device_resident_fan(lib):
     """pgr_env_destroy while a device-resident fan of the environment is still in flight: the release is deferred to the
     fan's own destruction (the fan uses the environment's stream, tables and buffer pool), so the fan still delivers --
@@ -1333,6 +1376,8 @@ def test_receiver_depths_searched_together_equal_one_search_each(lib):
     er_mod.LAST_SEARCH_STATS.clear()
     all4 = pr.find_eigenrays(fan, depths, 1000.0, 0.0, 300e3, 51, env, **kw)
     launches_together = er_mod.LAST_SEARCH_STATS["launches"]
+    # the re-shot eigenrays (trajectory kernel) end on the bits of the accepted trial rays (end-state kernel)
+    assert er_mod.LAST_SEARCH_STATS["reshot_differs"] == 0
     launches_alone = []
     for k, rd in enumerate(depths):
         er_mod.LAST_SEARCH_STATS.clear()

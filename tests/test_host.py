@@ -175,6 +175,23 @@ def test_rayfan_from_arrays_equals_list_constructor():
         np.testing.assert_array_equal(getattr(a, k), getattr(b, k))
 
 
+def test_rayfan_pickles_and_deep_copies_like_a_plain_object():
+    """The reference's RayFan is a plain object: pickle, copy.deepcopy and a trip to a multiprocessing worker keep every
+    attribute (a device-resident fan is fetched first: GPU test test_device_resident_fan_pickles_and_releases)."""
+    import copy
+    import pickle
+    a = RayFan(_make_rays(M=4))
+    lazy = RayFan.from_arrays(a.thetas, a.rs, a.ts, a.zs, a.ps, a.n_botts, a.n_surfs, a.source_depths)   # ray ids not built yet
+    for fan in (a, lazy):
+        for b in (pickle.loads(pickle.dumps(fan)), copy.deepcopy(fan)):
+            for k in ("thetas", "rs", "ts", "zs", "ps", "n_botts", "n_surfs", "source_depths", "ray_ids"):
+                np.testing.assert_array_equal(getattr(fan, k), getattr(b, k))
+            assert not b.device_resident and len(b) == 4 and isinstance(b[1], Ray)
+    assert a.to_host() is a
+    a.release()                     # no-ops on a host fan
+    assert a.zs.shape == (4, 10)
+
+
 def test_plots_smoke():
     import matplotlib
     matplotlib.use("Agg")
