@@ -69,6 +69,9 @@ def parse_args(argv=None):
                          "kernel ZM = 5): what pr.shoot_rays(...) integrates with the reference's default arguments; not the headline workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eigenray", action="store_true")
+    ap.add_argument("--blocked", action="store_true",
+                    help="(with --range-dependent) trajectories in the sample-blocked layout [S/4][N][4] (PGR_SAMPLE_BLOCKED): what the "
+                         "range_dependent leg's `trajectories` entry times")
     ap.add_argument("--no-legs", action="store_true", help="skip the extra kernel legs (flat-earth default grid, configs[2], 1e6 rays, lone wave)")
     ap.add_argument("--eigen-rays", type=int, default=1_000_000, help="fan size of the eigenray leg (configs[3])")
     ap.add_argument("--waves-per-block", type=int, default=0)
@@ -194,7 +197,7 @@ def _noop(_):
     return 0
 
 
-def kernel_leg(arrs, n_rays, save, passes=6, amin=-20.0, amax=20.0, rays_lo=None):
+def kernel_leg(arrs, n_rays, save, passes=6, amin=-20.0, amax=20.0, rays_lo=None, blocked=False):
     """One more workload through the same device entry, a few passes: kernel time from HIP events on the launch
     stream, accepted steps, the contract's algorithmic bytes and the fraction of the HBM peak they amount to."""
     import torch
@@ -205,7 +208,7 @@ def kernel_leg(arrs, n_rays, save, passes=6, amin=-20.0, amax=20.0, rays_lo=None
         theta = theta[rays_lo[0]:rays_lo[1]]
     env = _lib.EnvHandle(*arrs)
     y0 = fan_y0(arrs, SOURCE_DEPTH, 0.0, -theta)
-    fan = DeviceFan(env, y0, 0.0, RANGE_M, S_SAVE, save=save, sample_major=True)
+    fan = DeviceFan(env, y0, 0.0, RANGE_M, S_SAVE, save=save, sample_major=True, sample_blocked=blocked)
     for _ in range(3):     # (the clock has dropped while the host built this leg's tables: let it come back)
         fan.run()
     torch.cuda.synchronize()
@@ -245,8 +248,11 @@ def extra_legs():
     _, arrs_rd = munk_tables(RANGE_M, nr=101, sofar_slope=2e-4)
     legs["range_dependent"] = {
         "workload": "configs[2]: sofar axis + 2e-4 r over 101 columns, 1e5 rays, 1000 km",
-        "kernel": "pgr_fan_kernel<false, 4, SAVE> (tables in HBM / L2)",
-        "end_state": kernel_leg(arrs_rd, RAYS_PER_GPU, False), "trajectories": kernel_leg(arrs_rd, RAYS_PER_GPU, True)}
+        "kernel": "pgr_fan_kernel<false, 4, SAVE> (tables in HBM / L2); trajectories: SAVE = 3, the sample-blocked layout "
+                  "[S/4][N][4] (PGR_SAMPLE_BLOCKED: each lane stores four consecutive samples as one 32-byte piece per array); "
+                  "trajectories_row_layout: SAVE = 1, plain [S][N] rows",
+        "end_state": kernel_leg(arrs_rd, RAYS_PER_GPU, False), "trajectories": kernel_leg(arrs_rd, RAYS_PER_GPU, True, blocked=True),
+        "trajectories_row_layout": kernel_leg(arrs_rd, RAYS_PER_GPU, True)}
     _, arrs1 = munk_tables(RANGE_M)
     legs["rays_1e6"] = {
         "workload": "configs[1] tables, 1e6 launch angles (the per-GPU fan of configs[3] / configs[4]), end state only",
@@ -254,6 +260,60 @@ def extra_legs():
     lone = {"end_state": kernel_leg(arrs1, RAYS_PER_GPU, False, rays_lo=(0, 64)),
             "trajectories": kernel_leg(arrs1, RAYS_PER_GPU, True, rays_lo=(0, 64))}
     return legs, lone
+
+
+def config4_leg(env, arrs, rank, world, fence, passes=3, rays_per_gpu=1_000_000, bins=4096):
+    """BASELINE configs[4] as a leg of every N > 1 run (all ranks take part): 1e6 launch angles per GPU of the global
+    fan linspace(-20, 20, N x 1e6), dealt strided; end state only, the kernel writes the 40-byte end records itself;
+    each pass ends with the 4096-bin arrival-time histogram (HIP kernel + all-reduce of the counts) and the all-gather
+    of the end records, the gather of pass k travelling while pass k + 1 integrates.  Wall time = max over ranks
+    (barrier + synchronize on both sides).  Returns the leg on every rank (rank 0 prints it)."""
+    import torch
+    import torch.distributed as dist
+    from pygenray_amd.device_fan import DeviceFan, fan_y0
+    from pygenray_amd.distributed import shard_indices, start_all_gather_records, arrival_time_histogram
+    n_global = rays_per_gpu * world
+    theta = np.linspace(-20, 20, n_global)
+    idx = shard_indices(n_global, rank, world)
+    y0 = fan_y0(arrs, SOURCE_DEPTH, 0.0, -theta[idx])
+    n_pad = (n_global + world - 1) // world
+    fan = DeviceFan(env, y0, 0.0, RANGE_M, 1, save=False, packed_end=True, n_pad=n_pad)
+    t_lo, t_hi = RANGE_M / 1560.0, RANGE_M / 1400.0
+    hist, gathered = None, None
+
+    def one_pass(pending):
+        nonlocal hist, gathered
+        fan.run()
+        hist = arrival_time_histogram(fan.records[:fan.N, 0], fan.status, bins, t_lo, t_hi, reduce=True)
+        started = start_all_gather_records(fan.records, n_global)
+        if pending is not None:
+            gathered = pending.finish()
+        return started
+
+    pending = one_pass(None)
+    pending.finish()
+    fence()
+    t0 = time.perf_counter()
+    pending = None
+    for _ in range(passes):
+        pending = one_pass(pending)
+    gathered = pending.finish()
+    fence()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    ss = torch.tensor([fan.ray_steps(), int((fan.status != 0).sum().item())], dtype=torch.int64, device="cuda")
+    dist.all_reduce(ss, op=dist.ReduceOp.SUM)
+    end_all, _, _, st_all = gathered
+    ok_all = int((st_all == 0).sum().item())
+    return {"workload": f"configs[4]: {n_global} launch angles linspace(-20, 20) over {world} ranks ({rays_per_gpu} per GPU, strided), "
+                        "1000 km, end state only; per pass: fan kernel (40-byte end records written in place), 4096-bin arrival-time "
+                        "histogram + all-reduce, all-gather of the end records (overlapping the next pass)",
+            "ms_per_pass": float(tt.item()) / passes * 1e3, "passes": passes,
+            "ray_steps_per_pass": int(ss[0].item()), "ray_steps_per_s": int(ss[0].item()) * passes / float(tt.item()),
+            "dropped_rays": int(ss[1].item()), "gathered_rays": int(end_all.shape[0]), "gathered_ok": ok_all,
+            "histogram_counted_rays": int(hist.sum().item()), "histogram_bins": bins,
+            "all_gather_bytes_per_rank": n_pad * 40, "ranks": world}
 
 
 def eigenray_leg(env_obj, n_rays):
@@ -362,7 +422,8 @@ def main(argv=None):
             dist.init_process_group(args.backend)
         joined = torch.ones(1, device="cuda")
         dist.all_reduce(joined)
-        if int(joined.item()) != world:
+        ranks_joined = int(joined.item())
+        if ranks_joined != world:
             sys.exit(3)
 
     _lib.load()
@@ -381,7 +442,7 @@ def main(argv=None):
     save = not args.no_save
     # N > 1: the kernel writes the 40-byte end records of the all-gather itself (PGR_PACKED_END)
     fan = DeviceFan(env, y0, 0.0, RANGE_M, S_SAVE, save=save, sample_major=(args.layout == "sample"),
-                    packed_end=use_dist, n_pad=(n_global + world - 1) // world)
+                    packed_end=use_dist, n_pad=(n_global + world - 1) // world, sample_blocked=(args.blocked and save))
     HIST_BINS, T_LO, T_HI = 4096, RANGE_M / 1560.0, RANGE_M / 1400.0
     hist = None
 
@@ -463,6 +524,11 @@ def main(argv=None):
                        "config": "configs[3] sharded: pygenray_amd.distributed.shoot_rays_sharded (strided shards, all-gather "
                                  "of 40-byte end records) + find_eigenrays_sharded (brackets dealt to the ranks)"}
 
+    # configs[4] (1e6 rays per GPU, end records, histogram all-reduce, all-gather): a leg of every N > 1 run
+    cfg4 = None
+    if use_dist and world > 1 and not args.no_legs:
+        cfg4 = config4_leg(env, arrs, rank, world, fence)
+
     if rank == 0:
         value = total_steps * args.steps / dt
         # B_alg = 80 B (state in + out) + 24 B per saved (T,z,p) sample
@@ -483,7 +549,7 @@ def main(argv=None):
             try:
                 tj = json.load(open(tpath))
                 key = (("rangedep-" if args.range_dependent else "") + ("flatearth-" if args.flat_earth else "")
-                       + f"{args.layout}{'' if save else '-nosave'}")
+                       + ("blocked" if (args.blocked and save) else args.layout) + ("" if save else "-nosave"))
                 if key not in tj or tj[key].get("rays") != fan.N:
                     tnote = f"profiles/{tfiles[-1]} holds no PMC pass of this workload"
                 elif tj.get("device_code_sha256") != code_sha:
@@ -513,7 +579,7 @@ def main(argv=None):
                                    "linspace(-20,20), 1000 km, rtol 1e-9, fp64"
                                    + (", + 4096-bin arrival-time histogram (configs[4] shape)" if args.histogram else ""),
                        "rays_per_gpu": fan.N, "num_range_save": S_SAVE if save else 0,
-                       "trajectory_layout": args.layout if save else "none",
+                       "trajectory_layout": ("sample-blocked [S/4][N][4]" if args.blocked else args.layout) if save else "none",
                        "ray_steps_per_pass": total_steps, "dropped_rays": n_drop,
                        "histogram_bins": HIST_BINS if args.histogram else 0,
                        "sharding": ("strided launch angles, all-gather of end records" + (" -- REHEARSAL: all ranks share ONE GPU "
@@ -523,7 +589,7 @@ def main(argv=None):
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_gb_per_launch": traffic_gb, "traffic_source": tnote,
                          "algorithmic_gb_per_launch": local_steps * b_alg / 1e9,
-                         "kernel": f"pgr_fan_kernel<{'false' if args.range_dependent else 'true'}, {5 if args.flat_earth else 4}, {1 if save else 0}> "
+                         "kernel": f"pgr_fan_kernel<{'false' if args.range_dependent else 'true'}, {5 if args.flat_earth else 4}, {(3 if args.blocked else 1) if save else 0}> "
                                    f"(table in {'HBM/L2' if args.range_dependent else 'LDS'}, "
                                    f"{'non-uniform zin, cubic index estimate' if args.flat_earth else 'zin = j * 1 m'}, "
                                    f"{'linspace save grid' if save else 'end state only'})", "kernel_ms": kern_ms,
@@ -548,6 +614,10 @@ def main(argv=None):
             out["eigenray"] = eigenray_leg(env_obj, args.eigen_rays)
         if eig_sharded is not None:
             out["eigenray_sharded"] = eig_sharded
+        if use_dist:
+            out["ranks_joined"] = ranks_joined      # (from the all-reduce every rank took part in at start-up)
+        if cfg4 is not None:
+            out.setdefault("legs", {})["config4"] = cfg4
         if world == 1 and not args.no_legs:
             del fan   # (2.4 GB of trajectories back before the legs allocate theirs)
             legs, lone = extra_legs()

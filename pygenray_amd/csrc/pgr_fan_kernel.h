@@ -24,7 +24,8 @@
 // the memory half of each table look-up issued early with independent work behind it.
 // ------------------------------------------------------------------------------------
 // SAVE: 0 = end state only (no sample code); 1 = trajectories on a grid that IS np.linspace (recomputed
-// per index, no loads) with the default sample evaluation; 2 = any grid / PGR_EXACT_SAMPLES
+// per index, no loads) with the default sample evaluation; 2 = any grid / PGR_EXACT_SAMPLES; 3 = as 1, written in the
+// sample-blocked layout [ceil(S/4)][N][4] (PGR_SAMPLE_BLOCKED; instantiated for the HBM-table kernels only)
 template <bool LDS_TAB, int ZM, int SAVE>
 __global__ void __launch_bounds__(512)
 pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
@@ -90,7 +91,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
 #define SGN(v) __longlong_as_double(__double_as_longlong(v) ^ (long long)sgn)
     SaveGrid G;
     G.r = a.r_save; G.x0 = a.x0; G.x1 = a.x1; G.step = a.save_step;
-    G.S = S; G.formula = (SAVE == 1) ? 1 : a.save_formula;
+    G.S = S; G.formula = (SAVE == 1 || SAVE == 3) ? 1 : a.save_formula;
 
     double t = a.x0, y0 = 0, y1 = 0, y2 = 0;
     if (valid) {
@@ -129,30 +130,30 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     // of samples per fan must not evict the table rows), plain ones with the LDS table (measured faster there).
     // (Built, measured and not kept -- an LDS sample ring with a writer wave, a per-wave row ring, deferred stores:
     // scripts/experiments/r03_sample_store_experiments.patch.)
-    // PGR_SAMPLE_BLOCKED (HBM-table kernels): a lane stages its samples 4b ... 4b + 3 in its own LDS slots (no cross-lane
-    // protocol) and stores them itself when the fourth arrives, as one full 32-byte piece per array into [S/4][N][4].  A
-    // re-sample after a bounce rewrites at most sample jnext - 1 (REF/launch_rays.py:766-772): its slot still holds the
-    // block's other samples (nothing of the next block has been staged yet), so the block is simply stored again.
-#ifndef PGR_BLOCKED_SAMPLES
-#define PGR_BLOCKED_SAMPLES 1
-#endif
-    constexpr bool BLK = PGR_BLOCKED_SAMPLES && !LDS_TAB && SAVE != 0;
-    const bool blocked = BLK && (a.flags & PGR_SAMPLE_BLOCKED) != 0;
-    double* const blk = (double*)((char*)lds_tab + (BLK ? a.blk_lds_off : 0)) + (wv * 768 + (int)(threadIdx.x & 63));   // [slot][T, z, p][lane]
+    // SAVE == 3, PGR_SAMPLE_BLOCKED: a lane stages its samples 4b ... 4b + 3 in its OWN LDS slots (no cross-lane
+    // protocol: [T, z, p][slot][lane], 6 KB per wave) and stores them itself when the fourth arrives, as one full 32-byte
+    // piece per array into [S/4][N][4] -- half the store instructions of the row layout, no line written in pieces by
+    // different trips.  A re-sample after a bounce rewrites at most sample jnext - 1 (REF/launch_rays.py:766-772): the
+    // other slots still hold that block's samples (nothing of the next block has been staged yet), so the block is
+    // simply stored again.
+    constexpr bool BLK = (SAVE == 3);
+    static_assert(!(BLK && LDS_TAB), "the blocked sample layout is instantiated for the HBM-table kernels only");
+    double* const blk = (double*)((char*)lds_tab + (BLK ? a.blk_lds_off : 0)) + (wv * 768 + (int)(threadIdx.x & 63));
     auto blk_flush = [&](int jb) __attribute__((always_inline)) {
         const int64_t o = ((int64_t)jb * a.N + ray) * 4;
         typedef double d2 __attribute__((ext_vector_type(2)));
-        const d2 t0 = {blk[0], blk[192]}, t1 = {blk[384], blk[576]};
-        const d2 z0 = {blk[64], blk[256]}, z1 = {blk[448], blk[640]};
-        const d2 p0 = {blk[128], blk[320]}, p1 = {blk[512], blk[704]};
+        // (slots s and s + 1 of one array are 512 B apart: one ds_read2st64_b64 each, straight into a store's four registers)
+        const d2 t0 = {blk[0], blk[64]}, t1 = {blk[128], blk[192]};
+        const d2 z0 = {blk[256], blk[320]}, z1 = {blk[384], blk[448]};
+        const d2 p0 = {blk[512], blk[576]}, p1 = {blk[640], blk[704]};
         __builtin_nontemporal_store(t0, (d2*)(a.T + o)); __builtin_nontemporal_store(t1, (d2*)(a.T + o + 2));
         __builtin_nontemporal_store(z0, (d2*)(a.Z + o)); __builtin_nontemporal_store(z1, (d2*)(a.Z + o + 2));
         __builtin_nontemporal_store(p0, (d2*)(a.P + o)); __builtin_nontemporal_store(p1, (d2*)(a.P + o + 2));
     };
     auto emit_sample = [&](int j, double vt, double vz, double vp) __attribute__((always_inline)) {
-        if (BLK && blocked) {
-            double* const e = blk + (j & 3) * 192;
-            e[0] = vt; e[64] = vz; e[128] = vp;
+        if (BLK) {
+            double* const e = blk + (j & 3) * 64;
+            e[0] = vt; e[256] = vz; e[512] = vp;
             if ((j & 3) == 3) blk_flush(j >> 2);
             return;
         }
@@ -393,7 +394,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                             // makes every iteration wait (vmcnt) for the stores of the one before
                             // (every use of rnext is guarded by jnext < S - 1, so the formula copy needs no
                             // select for the forced last grid point)
-                            if (SAVE == 1 || G.formula) { PGR_SAMPLE_LOOP(grid_at(G.x0, G.step, jnext)) }
+                            if (SAVE == 1 || SAVE == 3 || G.formula) { PGR_SAMPLE_LOOP(grid_at(G.x0, G.step, jnext)) }
                             else { PGR_SAMPLE_LOOP(G.r[jnext]) }
 #undef PGR_SAMPLE_LOOP
 #undef PGR_KSUM
@@ -800,15 +801,15 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
             (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(kp));
         const FanArgs __attribute__((address_space(4))) & a = *(KArgs)(kp + kFanArgsKernargOffset);  // (shadows the argument)
-        if (save && BLK && blocked) {
+        if (BLK) {
             if (ok) {
                 // last column = exact final state (REF/launch_rays.py:775-777): into its slot, and the last block goes out
                 // (slots behind it hold an earlier block's samples: they land in the padding rows S ... 4 ceil(S/4) - 1)
-                double* const e = blk + ((S - 1) & 3) * 192;
-                e[0] = y0; e[64] = SGN(y1); e[128] = SGN(y2);
+                double* const e = blk + ((S - 1) & 3) * 64;
+                e[0] = y0; e[256] = SGN(y1); e[512] = SGN(y2);
                 blk_flush((S - 1) >> 2);
             } else {
-                for (int s4 = 0; s4 < 4; s4++) { blk[s4 * 192] = nan; blk[s4 * 192 + 64] = nan; blk[s4 * 192 + 128] = nan; }
+                for (int k = 0; k < 12; k++) blk[k * 64] = nan;
                 for (int jb = 0; jb < (S + 3) / 4; jb++) blk_flush(jb);
             }
         } else if (save) {

@@ -889,6 +889,7 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
     if (flags & PGR_SAMPLE_BLOCKED) {
         if (!save || !(flags & PGR_SAMPLE_MAJOR)) return fail("pgr_shoot_fan: PGR_SAMPLE_BLOCKED goes with trajectories and PGR_SAMPLE_MAJOR");
         if (lds_tab) return fail("pgr_shoot_fan: PGR_SAMPLE_BLOCKED is for environments whose tables stay in HBM (this one is on the LDS-table path)");
+        if (!a.save_formula || (flags & PGR_EXACT_SAMPLES)) return fail("pgr_shoot_fan: PGR_SAMPLE_BLOCKED needs a linspace save grid (PGR_SAVE_LINSPACE) and the default sample form");
         const size_t at = (lds + 15) & ~(size_t)15, need = (size_t)wpb * 6144;
         if (at + need > env->max_lds) return fail("pgr_shoot_fan: no LDS left for PGR_SAMPLE_BLOCKED");
         a.blk_lds_off = (int)at; lds = at + need;
@@ -907,7 +908,11 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
         else if (a.save_formula && !(flags & PGR_EXACT_SAMPLES)) PGR_LAUNCH1(LT, ZMV, 1);            \
         else PGR_LAUNCH1(LT, ZMV, 2);                                                                \
     } while (0)
-    if (lds_tab) {
+    if (flags & PGR_SAMPLE_BLOCKED) {   // (HBM-table path, trajectories, sample-major: checked above)
+        if (zm == 1) PGR_LAUNCH1(false, 1, 3); else if (zm == 2) PGR_LAUNCH1(false, 2, 3);
+        else if (zm == 3) PGR_LAUNCH1(false, 3, 3); else if (zm == 4) PGR_LAUNCH1(false, 4, 3); else if (zm == 5) PGR_LAUNCH1(false, 5, 3);
+        else PGR_LAUNCH1(false, 0, 3);
+    } else if (lds_tab) {
         if (zm == 1) PGR_LAUNCH(true, 1); else if (zm == 2) PGR_LAUNCH(true, 2);
         else if (zm == 3) PGR_LAUNCH(true, 3); else if (zm == 4) PGR_LAUNCH(true, 4); else if (zm == 5) PGR_LAUNCH(true, 5);
         else PGR_LAUNCH(true, 0);

@@ -21,5 +21,11 @@ for V in "" "flatearth" "rangedep"; do
   done
   rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_${P}sq -- $BENCH $F > $R/gpurun_out/${TAG}_${P}sq.log 2>&1
 done
+# configs[2] with trajectories in the sample-blocked layout (PGR_SAMPLE_BLOCKED, what the range_dependent leg times)
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_rangedep_blocked_stats -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-eigenray --no-legs --range-dependent --blocked > $R/gpurun_out/${TAG}_rangedep_blocked_stats.log 2>&1
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_rangedep_blocked_$C -- $BENCH --range-dependent --blocked > $R/gpurun_out/${TAG}_rangedep_blocked_$C.log 2>&1
+done
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_rangedep_blocked_sq -- $BENCH --range-dependent --blocked > $R/gpurun_out/${TAG}_rangedep_blocked_sq.log 2>&1
 python3 -c "import sys; sys.path.insert(0, '$R'); from pygenray_amd import _lib; import json; print(json.dumps({'device_code_sha256': _lib.device_code_sha256(), 'build': _lib.build_info()}))" > $R/gpurun_out/${TAG}_binary.json
 echo collected $TAG

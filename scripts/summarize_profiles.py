@@ -48,6 +48,22 @@ for variant, flag in (("", ""), ("flatearth", " --flat-earth"), ("rangedep", " -
         shutil.copy(st[0], os.path.join(ROOT, "profiles", f"{rnd}_kernel_stats{'_' + variant if variant else ''}.csv"))
         if not variant:
             print(open(st[0]).read())
+# configs[2] with trajectories in the sample-blocked layout
+fe = fan_counters(f"{tag}_rangedep_blocked_FETCH_SIZE").get("FETCH_SIZE")
+wr = fan_counters(f"{tag}_rangedep_blocked_WRITE_SIZE").get("WRITE_SIZE")
+if fe is not None and wr is not None:
+    out["rangedep-blocked"] = {"rays": 100000, "FETCH_SIZE_KB": fe, "WRITE_SIZE_KB": wr, "hbm_gb_per_launch": (2 * fe + wr) * 1024 / 1e9,
+                               "note": f"profiles/{rnd}_traffic.json: rocprofv3 PMC passes (FETCH_SIZE x 2 per the gfx950 correction + WRITE_SIZE), "
+                                       "fan kernel pgr_fan_kernel<false, 4, 3>, last dispatch",
+                               "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 3 "
+                                          "--warmup 1 --no-cpu-baseline --no-eigenray --no-legs --range-dependent --blocked"}
+    sq = fan_counters(f"{tag}_rangedep_blocked_sq")
+    if sq:
+        out["rangedep-blocked-sq_counters"] = sq
+        out["rangedep-blocked"]["valu_wave_instructions_per_launch"] = sq.get("SQ_INSTS_VALU")
+st = glob.glob(os.path.join(G, f"{tag}_rangedep_blocked_stats", "*", "*_kernel_stats.csv"))
+if st:
+    shutil.copy(st[0], os.path.join(ROOT, "profiles", f"{rnd}_kernel_stats_rangedep_blocked.csv"))
 b = os.path.join(G, f"{tag}_binary.json")
 if os.path.exists(b):
     out.update(json.load(open(b)))

@@ -622,7 +622,7 @@ def test_full_size_default_flat_earth_environment(lib):
 
 
 # ------------------------------------------------------------------ the benchmark AS IT IS BENCHMARKED: S = 1001 at 1000 km
-def _as_benchmarked(lib, arrs, label, every=50, exact_too=True):
+def _as_benchmarked(lib, arrs, label, every=50, exact_too=True, blocked=False):
     """bench.py's pass over one workload -- DeviceFan(env, y0, 0, 1000 km, S = 1001, sample-major [S][N] outputs left in
     HBM, ODE signs, linspace save grid recomputed on the device, default wave placement), 1e5 launch angles -- and every
     `every`-th ray of it against the oracle (MATH_CR): status / bounces / accepted and rejected steps / end state bit-equal;
@@ -642,11 +642,14 @@ def _as_benchmarked(lib, arrs, label, every=50, exact_too=True):
     tsub = torch.from_numpy(sub).cuda()
     stats = None
     for exact in ((False, True) if exact_too else (False,)):
-        fan = DeviceFan(env, y0, 0.0, x1, S, save=True, sample_major=True, exact_samples=exact)
+        fan = DeviceFan(env, y0, 0.0, x1, S, save=True, sample_major=True, exact_samples=exact, sample_blocked=(blocked and not exact))
         fan.run()
         torch.cuda.synchronize()
-        g = {"T": fan.T[:, tsub].T.cpu().numpy(), "z": fan.Z[:, tsub].T.cpu().numpy(), "p": fan.P[:, tsub].T.cpu().numpy(),
-             "end": fan.end[tsub].cpu().numpy()}
+        if fan.sample_blocked:     # [S/4][N][4] -> the compared rays' (n, S) trajectories
+            pick = lambda t: t[:, tsub, :].permute(1, 0, 2).reshape(len(sub), -1)[:, :S].cpu().numpy()   # noqa: E731
+        else:
+            pick = lambda t: t[:, tsub].T.cpu().numpy()   # noqa: E731
+        g = {"T": pick(fan.T), "z": pick(fan.Z), "p": pick(fan.P), "end": fan.end[tsub].cpu().numpy()}
         for k in ("n_bott", "n_surf", "status", "n_steps", "n_rej"):
             g[k] = getattr(fan, k)[tsub].cpu().numpy()
         st = assert_bit_parity(g, o, label=f"{label}, S = 1001, every {every}th ray" + (", SciPy sample order" if exact else ", default sample form"),
@@ -679,10 +682,75 @@ def test_config1_as_benchmarked_S1001(lib):
 
 
 def test_config2_as_benchmarked_S1001(lib):
-    """BASELINE configs[2] exactly as bench.py's `range_dependent` leg runs it: pgr_fan_kernel<false, 4, 1>."""
+    """BASELINE configs[2] exactly as bench.py's `range_dependent` leg runs it: `trajectories` = pgr_fan_kernel<false, 4, 3>
+    (the sample-blocked layout, PGR_SAMPLE_BLOCKED) and `trajectories_row_layout` = pgr_fan_kernel<false, 4, 1>."""
     import bench
-    st = _as_benchmarked(lib, bench.munk_tables(1000e3, nr=101, sofar_slope=2e-4)[1], "configs[2]")
+    arrs = bench.munk_tables(1000e3, nr=101, sofar_slope=2e-4)[1]
+    st = _as_benchmarked(lib, arrs, "configs[2], sample-blocked layout", blocked=True)
     assert st["n"] >= 1980 and st["bouncing"] > 500 and st["q5_samples"] > 1000
+    st = _as_benchmarked(lib, arrs, "configs[2], row layout", exact_too=False)
+    assert st["n"] >= 1980
+
+
+def test_sample_blocked_layout_holds_the_same_bits_as_the_row_layout(lib):
+    """PGR_SAMPLE_BLOCKED (HBM-table kernels, SAVE = 3): [ceil(S/4)][N][4] un-blocked equals the [S][N] rows of the
+    plain kernel bit for bit -- every S mod 4, dropped rays (NaN columns), bouncing rays (the re-sample after a bounce
+    rewrites a sample of a block already stored), every depth-search instance, the full configs[2] fan -- and the flag
+    is refused where it does not apply."""
+    import torch
+    from pygenray_amd.device_fan import DeviceFan, fan_y0
+    import pygenray_amd as pr
+    from pygenray_amd import _lib
+
+    def both(arrs, y0, x1, S):
+        env = lib.EnvHandle(*arrs)
+        assert not env.lds_path
+        out = []
+        for blocked in (False, True):
+            fan = DeviceFan(env, y0, 0.0, x1, S, save=True, sample_major=True, sample_blocked=blocked)
+            if blocked:
+                for t in (fan.T, fan.Z, fan.P):
+                    t.fill_(-7.0)                  # (padding rows must not matter; rows < S must all be written)
+            fan.run()
+            torch.cuda.synchronize()
+            out.append([fan.rows(t).cpu().numpy() for t in (fan.T, fan.Z, fan.P)] + [fan.end.cpu().numpy(), fan.status.cpu().numpy(),
+                                                                                   fan.n_steps.cpu().numpy()])
+            assert out[-1][0].shape == (S, len(y0))
+        env.close()
+        for a_, b_ in zip(*out):
+            assert np.array_equal(a_, b_, equal_nan=True)
+        return out[0]
+
+    # range-dependent Munk, table shallower than the sea floor: deep rays leave the table (dropped -> NaN columns)
+    zt = np.arange(0, 4200, 1.0)
+    arrs = munk_arrays(300e3, nr=41, z=zt, bathy=5000.0, sofar_slope=1e-3)
+    y0 = y0_for(oracle, arrs, 1000.0, 0.0, np.linspace(-20, 20, 700))
+    for S in (1, 2, 3, 4, 5, 6, 7, 8, 301, 302, 303, 304):
+        o = both(arrs, y0, 300e3, S)
+    assert 20 < (o[4] != 0).sum() < 600 and np.isnan(o[0][:, o[4] != 0]).all() and not np.isnan(o[0][:, o[4] == 0]).any()
+    # sloping bottom + every depth-search instance (uniform non-power-of-two grid, stretched grid, flat-earth grid)
+    for z in (np.linspace(0, 5500, 1377), 5500 * np.linspace(0, 1, 1200) ** 1.3, pr.eflat(np.arange(0, 5600, 2.0), 35.0)[0]):
+        r = np.linspace(0, 200e3, 33)
+        cin = np.array([munk(z, 1300 + 5e-4 * ri) for ri in r])
+        br = np.linspace(0, 200e3, 9)
+        depths = 4800 + 300 * np.sin(br / 40e3)
+        arrs2 = [cin, np.gradient(cin, z, axis=1, edge_order=1), r, z, depths, br, np.degrees(np.arctan(np.gradient(depths, br)))]
+        both(arrs2, y0_for(oracle, arrs2, 800.0, 0.0, np.linspace(-18, 18, 500)), 200e3, 203)
+    # configs[2] at full size
+    import bench
+    arrs3 = bench.munk_tables(1000e3, nr=101, sofar_slope=2e-4)[1]
+    o = both(arrs3, fan_y0(arrs3, 1000.0, 0.0, -np.linspace(-20, 20, 100_000)), 1000e3, 1001)
+    assert (o[4] != 0).sum() > 100 and int(o[5][o[4] == 0].sum()) > 1.2e8
+    # refused: an LDS-table environment; the SciPy sample order; ray-major output
+    env1 = lib.EnvHandle(*munk_arrays(100e3))
+    y1 = y0_for(oracle, munk_arrays(100e3), 1000.0, 0.0, np.linspace(-5, 5, 64))
+    with pytest.raises(_lib.PgrError):
+        DeviceFan(env1, y1, 0.0, 100e3, 11, save=True, sample_major=True, sample_blocked=True).run()
+    env2 = lib.EnvHandle(*arrs)
+    with pytest.raises(_lib.PgrError):
+        DeviceFan(env2, y0[:64], 0.0, 300e3, 11, save=True, sample_major=True, sample_blocked=True, exact_samples=True).run()
+    with pytest.raises(ValueError):
+        DeviceFan(env2, y0[:64], 0.0, 300e3, 11, save=True, sample_major=False, sample_blocked=True)
 
 
 def test_flat_earth_leg_as_benchmarked_S1001(lib):
