@@ -316,6 +316,38 @@ def config4_leg(env, arrs, rank, world, fence, passes=3, rays_per_gpu=1_000_000,
             "all_gather_bytes_per_rank": n_pad * 40, "ranks": world}
 
 
+def api_leg(env_obj, calls=3):
+    """What a `pr.shoot_rays` caller sees on configs[1] (1e5 launch angles, 1000 km, S = 1001): wall clock of the drop-in
+    call itself -- environment unpack, initial states, kernel, compaction of dropped rays, PCIe, RayFan -- eager
+    (`device_resident=False`: all three (M, S) arrays on the host when the call returns) and device resident (the
+    default for a fan this size: per-ray arrays and end states on the host, trajectories fetched when first read),
+    the best of the calls after the first (tables resident, buffers pooled).  This is the path that replaces the
+    reference's process pool + pickled Rays (REF/launch_rays.py:157-186)."""
+    import pygenray_amd as pr
+    angles = np.linspace(-20, 20, RAYS_PER_GPU)
+    kw = dict(debug=False, flatearth=False)
+    pr.shoot_rays(SOURCE_DEPTH, 0.0, angles[:1000], RANGE_M, S_SAVE, env_obj, **kw)      # table upload, library warm-up
+    out = {"workload": "pr.shoot_rays(1000 m, 0, linspace(-20, 20, 100000), 1000 km, 1001, env, flatearth=False): configs[1] through the drop-in API",
+           "calls": calls}
+    for name, mode in (("eager", False), ("device_resident", True)):
+        walls, reads = [], []
+        for _ in range(calls):
+            t0 = time.perf_counter()
+            fan = pr.shoot_rays(SOURCE_DEPTH, 0.0, angles, RANGE_M, S_SAVE, env_obj, device_resident=mode, **kw)
+            t1 = time.perf_counter()
+            nbytes = sum(a.nbytes for a in (fan.ts, fan.zs, fan.ps))       # (device resident: the three fetches happen here)
+            t2 = time.perf_counter()
+            walls.append(t1 - t0); reads.append(t2 - t1)
+            kept = len(fan)
+            del fan
+        out[name] = {"wall_ms": 1e3 * min(walls[1:]), "first_call_ms": 1e3 * walls[0],
+                     "then_reading_ts_zs_ps_ms": 1e3 * min(reads[1:]), "rays_kept": kept,
+                     "trajectory_bytes_to_host": int(nbytes),
+                     "bytes_to_host_inside_the_call": int(nbytes if not mode else kept * (3 * 8 + 8 + 4 + 4)),
+                     "pcie_floor_ms_at_56GBs": 1e3 * nbytes / 56e9}
+    return out
+
+
 def eigenray_leg(env_obj, n_rays):
     """BASELINE configs[3]: fixed source / receiver, a fan of n_rays launch angles (end state only)
     then pygenray's regula falsi on every bracket (REF/eigenrays.py:62-203), receiver depth 1000 m,
@@ -621,6 +653,7 @@ def main(argv=None):
         if world == 1 and not args.no_legs:
             del fan   # (2.4 GB of trajectories back before the legs allocate theirs)
             legs, lone = extra_legs()
+            legs["api"] = api_leg(env_obj)
             out["legs"] = legs
             # the fan cannot finish before its steepest rays do: the first wave of the fan (64 steepest rays) ALONE
             out["lone_wave_ms"] = {"end_state": lone["end_state"]["kernel_ms"], "trajectories": lone["trajectories"]["kernel_ms"],

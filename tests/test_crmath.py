@@ -83,8 +83,13 @@ def test_hard_neighbourhoods(crh):
     near 0.75), +-1 for asin), next to the table nodes j/32 of the double-double sine / cosine and next to the
     multiples of pi/2 of the sine's argument reduction."""
     k = np.arange(-30_000, 30_001, dtype=np.float64)
-    for n in (-3, -1, 0, 1, 2):                                   # 32^n (1 + k ulp): results next to 2^-n
+    for n in (-4, -3, -2, -1, 0, 1, 2, 3):                         # 32^n (1 + k ulp): results next to 2^-n ...
         x = 32.0 ** n * (1.0 + k * 2.0 ** -52)
+        assert np.array_equal(crh(0, x), oracle.math_fn("pow_m02", x)), n
+        assert np.array_equal(crh(1, x), oracle.math_fn("pow_p02", x)), n
+        # ... and EVERY double on the lower side, where they are twice as dense (the rounding test of the Ziv evaluation does
+        # not look at the finer spacing below a result that is a power of two: pgr_cr_rounding_uncertain)
+        x = 32.0 ** n * (1.0 - np.arange(0, 60_001) * 2.0 ** -53)
         assert np.array_equal(crh(0, x), oracle.math_fn("pow_m02", x)), n
         assert np.array_equal(crh(1, x), oracle.math_fn("pow_p02", x)), n
     for c in (0.0, 0.5, 0.75, 0.7499999, 0.9, 2.0 ** -27):
@@ -99,6 +104,51 @@ def test_hard_neighbourhoods(crh):
     for m in (1, 2, 3, 4):                                        # ... and the multiples of pi/2
         w = m * (np.pi / 2) * (1.0 + k * 2.0 ** -52)
         assert np.array_equal(crh(3, np.concatenate([w, -w])), oracle.math_fn("sin", np.concatenate([w, -w]))), m
+
+
+def test_powers_rounding_test_and_second_level(crh):
+    """The Ziv evaluation of the two powers (pgr_crmath.h): (i) the second level ALONE (logarithm in double precision,
+    rounding-limited root) is correctly rounded on every random argument, not only on the rare ones that reach it;
+    (ii) the rounding test sends a few in a million arguments there; (iii) EVERY argument it flagged in 6e9 (x ** -0.2) and
+    1.5e9 (x ** 0.2) random draws (tests/golden/g14_pow_hard_cases.npz, expected values from mpmath at 400 bits,
+    scripts/gen/gen_pow_hard_cases.py) comes out correctly rounded -- among them the cases whose exact value lies within
+    2^-80 of a rounding boundary, which the fast evaluation (good to 2^-74) cannot decide; (iv) the fast evaluation alone
+    (-DPGR_POW_NO_ZIV) does get some of the flagged ones wrong: the test is not vacuous."""
+    from helpers import load
+    rng = np.random.default_rng(4)
+    x = np.exp(rng.uniform(np.log(1e-7), np.log(1e4), N))
+    v = np.exp(rng.uniform(np.log(1e-15), np.log(1e13), N))
+    assert np.array_equal(crh(7, x), oracle.math_fn("pow_m02", x)) and np.array_equal(crh(8, v), oracle.math_fn("pow_p02", v))
+    assert np.abs(crh(9, v) - np.log2(v)).max() < 2.0 ** -45
+    for fn, arg in ((5, x), (6, v)):
+        frac = crh(fn, arg).mean()
+        assert 2e-7 < frac < 3e-5, (fn, frac)
+    g = load("g14_pow_hard_cases.npz")
+    for tag, fn, flag_fn, slow_fn in (("m02", 0, 5, 7), ("p02", 1, 6, 8)):
+        xs, want, dist = g[tag + "_x"], g[tag + "_want"], g[tag + "_log2_dist"]
+        assert len(xs) > 4000 and np.all(crh(flag_fn, xs) == 1.0)          # all of them take the second level
+        assert (dist < -80).sum() >= (24 if tag == "m02" else 6), (tag, int((dist < -80).sum()))
+        assert np.array_equal(crh(fn, xs), want), tag
+        assert np.array_equal(crh(slow_fn, xs), want), tag
+        assert np.array_equal(oracle.math_fn("pow_" + tag, xs), want), tag    # the oracle's binary128 agrees with mpmath
+
+
+def test_fast_power_alone_misrounds_some_flagged_arguments(tmp_path):
+    """(iv) above: the header built with -DPGR_POW_NO_ZIV (no rounding test) differs from the correctly rounded value on
+    some of the flagged arguments -- every one of them within 2^-74 of a boundary."""
+    from helpers import load
+    so = str(tmp_path / "libcrmath_noziv.so")
+    subprocess.check_call(["gcc", "-O2", "-std=gnu99", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-fopenmp",
+                           "-DPGR_POW_NO_ZIV", "-o", so, os.path.join(HERE, "crmath_host.c"), "-lm"])
+    L = ctypes.CDLL(so)
+    dp = ctypes.POINTER(ctypes.c_double)
+    g = load("g14_pow_hard_cases.npz")
+    xs = np.ascontiguousarray(g["m02_x"])
+    out = np.empty_like(xs)
+    L.crh_eval(ctypes.c_int(0), xs.ctypes.data_as(dp), out.ctypes.data_as(dp), ctypes.c_int64(xs.size))
+    wrong = out != g["m02_want"]
+    assert 0 < wrong.sum() < 0.2 * len(xs)
+    assert g["m02_log2_dist"][wrong].max() < -74 and np.all(np.abs(out[wrong] - g["m02_want"][wrong]) <= np.spacing(g["m02_want"][wrong]))
 
 
 def test_the_platform_libm_is_faithful_but_not_correctly_rounded():

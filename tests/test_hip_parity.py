@@ -843,6 +843,26 @@ def test_arithmetic_building_blocks(lib):
         # (column 1, the bare Newton reciprocal, only ever SEEDS such quotients in the kernel: not required here)
 
 
+def test_powers_hard_cases_on_the_device(lib):
+    """The Ziv evaluation of err ** -0.2 and (0.01 / d) ** 0.2 ON THE DEVICE (csrc/pgr_crmath.h): every argument the
+    rounding test flagged in 6e9 / 1.5e9 random draws (tests/golden/g14_pow_hard_cases.npz; expected values from mpmath at
+    400 bits), among them >= 24 whose exact power lies within 2^-80 of a rounding boundary -- bit-equal; padded to whole
+    waves with easy arguments, and alone in a wave (the second level runs behind a wave-uniform ballot)."""
+    g = load("g14_pow_hard_cases.npz")
+    rng = np.random.default_rng(14)
+    for tag, col in (("m02", 4), ("p02", 6)):
+        xs, want, dist = g[tag + "_x"], g[tag + "_want"], g[tag + "_log2_dist"]
+        assert (dist < -80).sum() >= (24 if tag == "m02" else 6)
+        out = lib.debug_math(np.ones(len(xs)), xs)[:, col]
+        assert np.array_equal(out, want), (tag, int((out != want).sum()))
+        # one hard argument per wave among 63 easy ones
+        hard = xs[np.argsort(dist)[:64]]
+        b = rng.uniform(0.05, 1.0, 64 * 64)
+        b[::64] = hard
+        out = lib.debug_math(np.ones(len(b)), b)[:, col]
+        assert np.array_equal(out, oracle.math_fn("pow_" + tag, b)) and np.array_equal(out[::64], want[np.argsort(dist)[:64]])
+
+
 def test_step_probe_reproduces_the_oracle_trace(lib):
     """Every step ATTEMPT of a ray, one at a time: the device's rk_step + error norm + controller
     power from the oracle's (t, y, h) must give the oracle's y_new, f_new, error_norm and power bit
