@@ -122,7 +122,7 @@ def test_powers_rounding_test_and_second_level(crh):
     assert np.abs(crh(9, v) - np.log2(v)).max() < 2.0 ** -45
     for fn, arg in ((5, x), (6, v)):
         frac = crh(fn, arg).mean()
-        assert 2e-7 < frac < 3e-5, (fn, frac)
+        assert frac < 3e-5 and (frac > 2e-7 or N < 1_000_000), (fn, frac)     # (expected 3e-6; the sanitizer run draws 2e5)
     g = load("g14_pow_hard_cases.npz")
     for tag, fn, flag_fn, slow_fn in (("m02", 0, 5, 7), ("p02", 1, 6, 8)):
         xs, want, dist = g[tag + "_x"], g[tag + "_want"], g[tag + "_log2_dist"]
