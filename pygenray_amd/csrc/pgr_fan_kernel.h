@@ -136,6 +136,8 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     // different trips.  A re-sample after a bounce rewrites at most sample jnext - 1 (REF/launch_rays.py:766-772): the
     // other slots still hold that block's samples (nothing of the next block has been staged yet), so the block is
     // simply stored again.
+    // (Tried in the LDS-table kernels too, round 4: headline fan 5.86 against 5.70 ms, its lone steepest wave 5.40 against
+    // 5.27 ms -- there the plain stores cost nothing to issue and the staging is pure overhead.  HBM-table instances only.)
     constexpr bool BLK = (SAVE == 3);
     static_assert(!(BLK && LDS_TAB), "the blocked sample layout is instantiated for the HBM-table kernels only");
     double* const blk = (double*)((char*)lds_tab + (BLK ? a.blk_lds_off : 0)) + (wv * 768 + (int)(threadIdx.x & 63));
