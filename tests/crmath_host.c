@@ -28,7 +28,8 @@ static double ziv_flag_m02(double x)
     const double dh = ch * x, dl = __builtin_fma(cl, x, __builtin_fma(ch, x, -dh));
     const double rho = (1.0 - dh) - dl, r5 = rho * 0.2;
     const double u = __builtin_fma((double)lf, PGR_CR_POW_KLN2, __builtin_fma(-2.0 * r5, r5, r5));
-    return (double)pgr_cr_rounding_uncertain(y, y * u, y + y * u);
+    const double r = __builtin_fma(y, u, y);
+    return (double)pgr_cr_rounding_uncertain(__builtin_fma(y, u, -(r - y)), r);
 }
 static double slow_m02(double x)
 {
@@ -41,7 +42,7 @@ static double p02_parts(double x, int slow, int flag)
     double w = (double)pgr_cr_seed_exp2f(-0.2f * lf), approx, corr;
     w = pgr_cr_newton5(x, pgr_cr_newton5(x, w, 0.2), 0.2);
     const double r = pgr_cr_pow_p02_eval(x, w, slow ? pgr_cr_log2_slow(x) : (double)lf, &approx, &corr);
-    return flag ? (double)pgr_cr_rounding_uncertain(approx, corr, r) : r;
+    return flag ? (double)pgr_cr_rounding_uncertain((approx - r) + corr, r) : r;
 }
 void crh_eval(int fn, const double *a, double *out, int64_t n)
 {
