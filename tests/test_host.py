@@ -565,6 +565,34 @@ def test_round3_profiles_name_the_binary_and_bench_line_carries_the_legs():
         assert "device_code_sha256" in d["roofline"]["traffic_source"] or "no PMC pass" in d["roofline"]["traffic_source"]
 
 
+def test_round4_profiles_and_bench_line():
+    """profiles/r04_*: PMC passes that name their binary (incl. the sample-blocked configs[2] kernel and its halved write
+    traffic), the instruction budget, the all-rays S = 1001 parity log, and the committed bench line with the api leg."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tr = json.load(open(os.path.join(root, "profiles", "r04_traffic.json")))
+    assert len(tr["device_code_sha256"]) == 64 and tr["build"].startswith("layout: relaid")
+    assert tr["rangedep-blocked"]["WRITE_SIZE_KB"] * 1024 / 1e9 <= 2.9 < tr["rangedep-sample"]["WRITE_SIZE_KB"] * 1024 / 1e9
+    for v, tag in (("", "<true, 4, 1>"), ("_flatearth", "<true, 5, 1>"), ("_rangedep", "<false, 4, 1>"), ("_rangedep_blocked", "<false, 4, 3>")):
+        assert "pgr_fan_kernel" + tag in open(os.path.join(root, "profiles", f"r04_kernel_stats{v}.csv")).read(), v
+    b = json.load(open(os.path.join(root, "profiles", "r04_isa_budget.json")))
+    assert b["device_code_sha256"] == tr["device_code_sha256"]
+    pt = b["derived"]["headline"]["per_wave_trip"]
+    assert 600 < pt["SQ_INSTS_VALU"] < 800 and 11.9 < pt["SQ_INSTS_LDS"] < 12.1 and pt["lane_utilisation"] > 0.98
+    log = open(os.path.join(root, "profiles", "r04_bitparity_S1001.txt")).read()
+    assert log.count("all 1001 samples (SciPy order) 1.00000") == 9 and log.count("bit-equal True") >= 3 and "0.99" not in log.split("default sample")[0]
+    d = json.load(open(os.path.join(root, "profiles", "r04_bench_line.json")))
+    assert d["device_code_sha256"] == tr["device_code_sha256"] and d["roofline"]["traffic"] is not None
+    assert set(d["legs"]) == {"flatearth_default", "range_dependent", "rays_1e6", "api"}
+    rd = d["legs"]["range_dependent"]
+    assert rd["trajectories"]["kernel_ms"] < rd["trajectories_row_layout"]["kernel_ms"]
+    api = d["legs"]["api"]
+    assert api["device_resident"]["wall_ms"] < api["eager"]["wall_ms"] and api["eager"]["trajectory_bytes_to_host"] > 2e9
+    reh = json.load(open(os.path.join(root, "profiles", "r04_bench_line_4ranks_one_gpu_rehearsal.json")))
+    assert reh["ranks_joined"] == 4 and reh["legs"]["config4"]["gathered_rays"] == 4_000_000
+    assert reh["legs"]["config4"]["histogram_counted_rays"] == reh["legs"]["config4"]["gathered_ok"]
+
+
 def test_device_code_hash_reads_the_built_library():
     """_lib.device_code_sha256: the gfx950 .text inside the library's fat binary (no GPU needed)."""
     from pygenray_amd import _lib
