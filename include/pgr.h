@@ -80,8 +80,9 @@ extern "C" {
 #define PGR_SAMPLE_BLOCKED 2048u   /* (with PGR_SAMPLE_MAJOR; environments whose tables stay in HBM / L2) T / z / p are written as
                                      [ceil(S / 4)][N][4]: sample j of ray k at ((j / 4) * N + k) * 4 + j % 4 -- every lane stages four
                                      consecutive samples in LDS and stores them as one full 32-byte piece per array.  The buffers hold
-                                     4 * ceil(S / 4) * N doubles (rows S ... 4 * ceil(S / 4) - 1 are padding).  An error for environments
-                                     on the LDS-table path. */
+                                     4 * ceil(S / 4) * N doubles (rows S ... 4 * ceil(S / 4) - 1 are padding).  pgr_shoot_fan_device only
+                                     (a layout for device-resident consumers), with PGR_SAVE_LINSPACE and the default sample form; an
+                                     error for environments on the LDS-table path and in the host-pointer / fan-handle entries. */
 #define PGR_LAUNCH_SLOWNESS 1024u   /* (pgr_fan_launch without y0) the array of launch angles holds the initial vertical
                                       slowness p0[k] = sin(radians(angle_k)) / c_source itself, computed by the caller
                                       (REF/launch_rays.py:144): y0[k] = [0, source_depth, p0[k]] is assembled on the device */

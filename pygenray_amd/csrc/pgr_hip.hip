@@ -1153,6 +1153,8 @@ extern "C" int pgr_shoot_fan(pgr_env* env, const double* y0, int64_t N, double s
     if (!y0 || !n_bott || !n_surf || !status) return fail("pgr_shoot_fan: null argument");
     bool save = (T != nullptr);
     if (save && (!z || !p || !r_save || S < 1)) return fail("pgr_shoot_fan: T, z, p, r_save, S go together");
+    // (the blocked layout is a device-side layout: its buffers hold 4 ceil(S/4) N doubles, this entry's hold S N)
+    if (flags & PGR_SAMPLE_BLOCKED) return fail("pgr_shoot_fan: PGR_SAMPLE_BLOCKED is for pgr_shoot_fan_device (device-resident consumers)");
     HIPCHK(hipSetDevice(env->device));
     std::lock_guard<std::mutex> lock(env->ws_mutex);
     size_t ns_bytes = (size_t)N * (size_t)(save ? S : 0) * sizeof(double);
@@ -1349,6 +1351,7 @@ extern "C" int pgr_fan_launch(pgr_env* env, const double* y0, const double* ode_
     if (N <= 0) return fail("pgr_fan_launch: need at least one ray");
     if (!y0 && !ode_angles_deg) return fail("pgr_fan_launch: give y0 or launch angles");
     if (S < 0) return fail("pgr_fan_launch: negative num_range_save");
+    if (flags & PGR_SAMPLE_BLOCKED) return fail("pgr_fan_launch: PGR_SAMPLE_BLOCKED is for pgr_shoot_fan_device (device-resident consumers)");
     HIPCHK(hipSetDevice(env->device));
     if (!env->stream) {
         std::lock_guard<std::mutex> lock(env->ws_mutex);

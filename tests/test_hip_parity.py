@@ -751,6 +751,19 @@ def test_sample_blocked_layout_holds_the_same_bits_as_the_row_layout(lib):
         DeviceFan(env2, y0[:64], 0.0, 300e3, 11, save=True, sample_major=True, sample_blocked=True, exact_samples=True).run()
     with pytest.raises(ValueError):
         DeviceFan(env2, y0[:64], 0.0, 300e3, 11, save=True, sample_major=False, sample_blocked=True)
+    # ... and in the host-pointer entry, whose buffers are [S][N]
+    import ctypes
+    L = _lib.load()
+    S_, n_ = 11, 64
+    r_ = np.linspace(0.0, 300e3, S_)
+    bufs = [np.empty((S_, n_)) for _ in range(3)]
+    ints = [np.zeros(n_, np.int32) for _ in range(5)]
+    end_ = np.empty((n_, 3))
+    vp = lambda a_: a_.ctypes.data_as(ctypes.c_void_p)   # noqa: E731
+    rc = L.pgr_shoot_fan(env2._h, vp(np.ascontiguousarray(y0[:n_])), n_, 0.0, 300e3, vp(r_), S_, 1e-9, 1e-6,
+                         _lib.PGR_SAMPLE_MAJOR | _lib.PGR_SAMPLE_BLOCKED, 10**6, vp(bufs[0]), vp(bufs[1]), vp(bufs[2]), vp(end_),
+                         vp(ints[0]), vp(ints[1]), vp(ints[2]), vp(ints[3]), vp(ints[4]))
+    assert rc != 0 and b"PGR_SAMPLE_BLOCKED" in L.pgr_last_error()
 
 
 def test_flat_earth_leg_as_benchmarked_S1001(lib):
