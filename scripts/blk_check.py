@@ -1,6 +1,6 @@
 """PGR_SAMPLE_BLOCKED against the plain sample-major layout: same bits, and the timing of both (configs[2], S = 1001)."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import bench
