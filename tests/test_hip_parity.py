@@ -1300,6 +1300,34 @@ def test_sharded_api_two_ranks_on_one_gpu_equal_the_single_process_api(lib, tmp_
             assert np.array_equal(g[f"e{k}_failed"], np.array(er1.failed_eray_theta_brackets[k], dtype=float).reshape(-1, 2))
 
 
+def test_bench_two_ranks_on_one_gpu_carries_the_multi_gpu_legs(lib):
+    """`python bench.py --gpus 2` end to end, the way the driver's N > 1 runs go (the launcher starts the ranks, rank 0 prints ONE
+    JSON line) -- rehearsed on this box's one GPU over gloo (PGR_BENCH_ONE_GPU=1: RCCL wants one GPU per rank): the line
+    carries `ranks_joined`, the configs[4] leg (1e6 rays per rank, end records all-gathered, histogram all-reduced: every
+    surviving ray counted once) and the sharded eigenray search; its whole-job value is steps x passes / wall."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PGR_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1",
+                        "--eigen-rays", "200000"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_joined"] == 2 and d["scaling"] == "weak" and "REHEARSAL" in d["config"]["sharding"]
+    assert abs(d["value"] - d["config"]["ray_steps_per_pass"] * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
+    assert 2.8e8 < d["config"]["ray_steps_per_pass"] < 3.0e8          # 2 x 1e5 rays of the 2e5-angle fan
+    c4 = d["legs"]["config4"]
+    assert c4["ranks"] == 2 and c4["gathered_rays"] == 2_000_000 and c4["histogram_counted_rays"] == c4["gathered_ok"]
+    assert c4["gathered_ok"] == 2_000_000 - c4["dropped_rays"] and 2.8e9 < c4["ray_steps_per_pass"] < 3.0e9
+    es = d["eigenray_sharded"]
+    assert es["ranks"] == 2 and es["found"] + es["failed"] == es["brackets"] and es["found"] > 10
+    assert "cpu_baseline" not in d and "api" not in d.get("legs", {})      # rank-0-at-N=1-only legs stay out
+
+
 def test_arrival_time_histogram_equals_numpy(lib):
     """pgr_arrival_histogram_device (BASELINE configs[4]) against np.histogram, count for count:
     values on bin edges and on the range ends, NaN, dropped rays, strided views, packed end records."""
