@@ -210,6 +210,20 @@ int pgr_eigen_refine_depths(pgr_env* env, int64_t nbk, const double* th1, const 
                             int64_t max_steps, double ztol, int32_t max_iter, double* theta, int32_t* state,
                             int32_t* n_trial, double* z_end, double* t_end, int32_t* launches);
 
+/* ... and with the trial rays' initial slowness computed by the CALLER: `slowness(ode_angles_deg, n, p0_out, user)` must set
+ * p0_out[k] = sin(radians(ode_angles_deg[k])) / c_source for k < n (HOST arrays; a NaN angle -- a finished bracket -- must give
+ * a NaN) with the caller's own sine.  pygenray computes every initial slowness with NumPy's sine (REF/launch_rays.py:284-285),
+ * which is faithful, not correctly rounded: the Python shim passes NumPy's here, so that a trial ray, the eigenray handed back and
+ * shoot_ray(theta) of the same angle all start from the SAME bits, the reference's.  Costs one small D2H + H2D per iteration.
+ * slowness == NULL: the device's correctly rounded sine, as pgr_eigen_refine_depths. */
+typedef void (*pgr_slowness_fn)(const double* ode_angles_deg, int64_t n, double* p0_out, void* user);
+int pgr_eigen_refine_depths_fn(pgr_env* env, int64_t nbk, const double* th1, const double* th2, const double* z1,
+                               const double* z2, const double* receiver_depths, double source_depth, double source_range,
+                               double receiver_range, double c_source, double rtol, double atol, uint32_t flags,
+                               int64_t max_steps, double ztol, int32_t max_iter, double* theta, int32_t* state,
+                               int32_t* n_trial, double* z_end, double* t_end, int32_t* launches,
+                               pgr_slowness_fn slowness, void* slowness_user);
+
 /* Arrival-time histogram of a fan's surviving rays on the device (BASELINE configs[4]; the
  * reduction behind pygenray's time-front scatter RayFan.plot_time_front, REF/ray_objects.py:157-222;
  * no reference counterpart for the binning itself, so it is NumPy's):
@@ -239,11 +253,17 @@ int pgr_arrival_histogram_device(int device, const double* t_end, int64_t t_stri
  *                            of them wait or the oldest waited `b` step attempts (default 64, 10)
  *   PGR_OPT_PLACEMENT        cost-aware wave scheduling for fans of 1-2 waves per SIMD: a = 2 (default) the
  *                            costliest waves get a SIMD to themselves / are paired with the cheapest, plus
- *                            issue priorities by cost quartile; 1 = priorities only; 0 = strided deal */
+ *                            issue priorities by cost quartile; 1 = priorities only; 0 = strided deal
+ *   PGR_OPT_PERSISTENT       fans of several rounds (more 64-ray packets than the chip holds waves): a = 1 (default)
+ *                            one workgroup per CU whose waves claim packet after packet from the cost-sorted list
+ *                            (most expensive first) with one atomic each; a = 0 the static deal of whole
+ *                            cost-sorted workgroups (what replaces the reference's pool.imap over single rays,
+ *                            REF/launch_rays.py:157-164, either way) */
 #define PGR_OPT_WAVES_PER_BLOCK 0
 #define PGR_OPT_DEPTH_SEARCH 1
 #define PGR_OPT_PARK 2
 #define PGR_OPT_PLACEMENT 3
+#define PGR_OPT_PERSISTENT 4
 int pgr_env_set_option(pgr_env* env, int what, int a, int b);
 
 /* Unit-level device entry points (for parity tests of a1-a8, REF/integration_processes.py):

@@ -124,7 +124,7 @@ def _relayout(td, verbose):
 
 
 def build(force=False, verbose=False, out=None, extra_flags=()):
-    """Compile csrc/pgr_hip.hip (+ pgr_device.h, pgr_fan_kernel.h, pgr_crmath.h) for gfx950 (cross-compiles without a GPU): hipcc, then the
+    """Compile csrc/pgr_hip.hip (ONE translation unit; it includes every csrc/*.h) for gfx950 (cross-compiles without a GPU): hipcc, then the
     instruction-layout pass over its assembly (_relayout; PGR_NO_RELAYOUT=1 or any failure of that
     pass leaves the plain hipcc build in place).  `out` / `extra_flags`: build a variant library
     somewhere else (A/B experiments, scripts/kbench.py --lib); the default builds the product."""
@@ -133,8 +133,9 @@ def build(force=False, verbose=False, out=None, extra_flags=()):
     LIB_PATH = out or globals()["LIB_PATH"]
     src = os.path.join(CSRC, "pgr_hip.hip")
     hdr = os.path.join(_HERE, "..", "include", "pgr.h")
-    deps = [src, hdr, os.path.join(_HERE, "_isa_layout.py")] + [
-        os.path.join(CSRC, h) for h in ("pgr_crmath.h", "pgr_device.h", "pgr_fan_kernel.h")]
+    # (one translation unit: pgr_hip.hip includes every csrc/*.h -- device building blocks, the fan kernel, the host side in pieces)
+    deps = [src, hdr, os.path.join(_HERE, "_isa_layout.py")] + sorted(
+        os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h"))
     if not force and os.path.exists(LIB_PATH):
         if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
             return LIB_PATH
@@ -255,7 +256,7 @@ class EnvHandle:
         return load().pgr_env_query(self._h, int(what))
 
     # tuning options of this environment (include/pgr.h; results never depend on them)
-    _OPTIONS = {"waves_per_block": 0, "depth_search": 1, "park": 2, "placement": 3}
+    _OPTIONS = {"waves_per_block": 0, "depth_search": 1, "park": 2, "placement": 3, "persistent": 4}
 
     def set_option(self, name, a, b=0):
         check(load().pgr_env_set_option(self._h, self._OPTIONS[name], int(a), int(b)))
@@ -343,10 +344,12 @@ class EnvHandle:
         return out
 
     def eigen_refine(self, th1, th2, z1, z2, receiver_depth, source_depth, source_range, receiver_range, c_source,
-                     rtol=1e-9, atol=1e-6, terminate_backwards=True, max_steps=1_000_000, ztol=1.0, max_iter=20):
-        """pgr_eigen_refine_depths: the false-position loop of REF/eigenrays.py:206-268 for all brackets, on the device.
+                     rtol=1e-9, atol=1e-6, terminate_backwards=True, max_steps=1_000_000, ztol=1.0, max_iter=20,
+                     slowness=None):
+        """pgr_eigen_refine_depths_fn: the false-position loop of REF/eigenrays.py:206-268 for all brackets, on the device.
         `receiver_depth`: one depth for all brackets, or one per bracket (the brackets of several receiver depths
-        searched together)."""
+        searched together).  `slowness(ode_angles_deg) -> p0`: the caller's sin(radians(.)) / c for the trial rays (the shim
+        passes NumPy's, the reference's arithmetic); None: the device's correctly rounded sine."""
         L = load()
         th1, th2, z1, z2 = (_c(a).reshape(-1) for a in (th1, th2, z1, z2))
         n = len(th1)
@@ -354,14 +357,28 @@ class EnvHandle:
         theta = np.full(n, np.nan); zend = np.full(n, np.nan); tend = np.full(n, np.nan)
         state = np.zeros(n, np.int32); ntrial = np.zeros(n, np.int32)
         launches = ctypes.c_int32(0)
-        L.pgr_eigen_refine_depths.restype = ctypes.c_int
-        L.pgr_eigen_refine_depths.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp, _vp] + [ctypes.c_double] * 6 + [
-            ctypes.c_uint32, _i64, ctypes.c_double, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_int32)]
-        check(L.pgr_eigen_refine_depths(self._h, n, _vptr(th1), _vptr(th2), _vptr(z1), _vptr(z2), _vptr(rd),
-                                 float(source_depth), float(source_range), float(receiver_range), float(c_source),
-                                 float(rtol), float(atol), PGR_TERMINATE_BACKWARDS if terminate_backwards else 0,
-                                 int(max_steps), float(ztol), int(max_iter), _vptr(theta), _vptr(state), _vptr(ntrial),
-                                 _vptr(zend), _vptr(tend), ctypes.byref(launches)))
+        FN = ctypes.CFUNCTYPE(None, _dp, _i64, _dp, _vp)
+        L.pgr_eigen_refine_depths_fn.restype = ctypes.c_int
+        L.pgr_eigen_refine_depths_fn.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp, _vp] + [ctypes.c_double] * 6 + [
+            ctypes.c_uint32, _i64, ctypes.c_double, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_int32),
+            FN, _vp]
+        failure = []
+
+        def _cb(ang_p, m, out_p, _user):
+            try:    # (an exception must not unwind through the C frames: it is re-raised when the call has returned)
+                ang = np.ctypeslib.as_array(ang_p, shape=(m,))
+                np.ctypeslib.as_array(out_p, shape=(m,))[:] = slowness(ang)
+            except BaseException as exc:   # noqa: BLE001
+                failure.append(exc)
+                np.ctypeslib.as_array(out_p, shape=(m,))[:] = np.nan
+        cb = FN(_cb) if slowness is not None else ctypes.cast(None, FN)
+        check(L.pgr_eigen_refine_depths_fn(self._h, n, _vptr(th1), _vptr(th2), _vptr(z1), _vptr(z2), _vptr(rd),
+                                           float(source_depth), float(source_range), float(receiver_range), float(c_source),
+                                           float(rtol), float(atol), PGR_TERMINATE_BACKWARDS if terminate_backwards else 0,
+                                           int(max_steps), float(ztol), int(max_iter), _vptr(theta), _vptr(state), _vptr(ntrial),
+                                           _vptr(zend), _vptr(tend), ctypes.byref(launches), cb, None))
+        if failure:
+            raise failure[0]
         return dict(theta=theta, state=state, n_trial=ntrial, z_end=zend, t_end=tend, launches=int(launches.value))
 
     def eval_points(self, x, y):

@@ -92,6 +92,10 @@ struct FanArgs {
     int64_t max_steps;
     uint32_t flags;
     int blk_lds_off;      // PGR_SAMPLE_BLOCKED: byte offset of the per-lane sample staging area in LDS (768 doubles per wave)
+    // persistent waves (fans of several rounds): wave_map[0 .. n_queue) is the list of 64-ray packets, most expensive
+    // first; a wave claims the next one with atomicAdd(wave_queue, 1) until the list is empty.  Null: one packet per wave.
+    int* wave_queue;
+    int n_queue;
 };
 
 // The fan kernel's service phase and epilogue re-read FanArgs from the kernel-argument segment (so that what only they
@@ -414,6 +418,10 @@ struct Ctx {
           h_row_stride(e_.row_stride), h_z_uniform(e_.z_uniform), h_z_pow2(e_.z_pow2), h_z0(e_.z0),
           h_zin(e_.zin),
           h_rin(e_.rin), h_nz(e_.nz), h_nr(e_.nr), h_r_uniform(e_.r_uniform)
+    {
+        r_lo = 1.0; r_hi = 0.0; r_yden = 1.0; r_hi2 = 0.0; r_i = 0;  // empty interval: first use refills
+    }
+    __device__ __forceinline__ void reset_range_cache() const
     {
         r_lo = 1.0; r_hi = 0.0; r_yden = 1.0; r_hi2 = 0.0; r_i = 0;  // empty interval: first use refills
     }

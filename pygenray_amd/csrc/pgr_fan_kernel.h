@@ -26,7 +26,9 @@
 // SAVE: 0 = end state only (no sample code); 1 = trajectories on a grid that IS np.linspace (recomputed
 // per index, no loads) with the default sample evaluation; 2 = any grid / PGR_EXACT_SAMPLES; 3 = as 1, written in the
 // sample-blocked layout [ceil(S/4)][N][4] (PGR_SAMPLE_BLOCKED; instantiated for the HBM-table kernels only)
-template <bool LDS_TAB, int ZM, int SAVE>
+// PERSIST: persistent waves claiming 64-ray packets from the cost-sorted list (fans of several rounds; see the packet loop
+// below); false: one packet per wave, and the loop folds away -- the instances the 1e5-ray fans run are the code they were
+template <bool LDS_TAB, int ZM, int SAVE, bool PERSIST>
 __global__ void __launch_bounds__(512)
 pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
 {
@@ -60,22 +62,54 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     __syncthreads();
     const Ctx<LDS_TAB, ZM> C(env, lds_tab, lds_z, lds_zb, lds_bx);
     C.declare_span(a.x0, a.x1);
+    // PERSISTENT WAVES (a.wave_queue, fans of several rounds): the grid is one workgroup per CU, the table is staged into
+    // the LDS once, and every wave of it integrates one 64-ray PACKET after the other -- the next entry of the
+    // cost-sorted list pgr_wave_place wrote (most expensive first), claimed with one atomic -- until the list is
+    // empty.  A workgroup with the 96 KB table holds its CU until its LAST wave ends; dealt whole workgroups of
+    // packets (the static mode 3) the SIMD slots of the waves that end early idle until then, and the chip drains
+    // workgroup by workgroup at the end of the launch.  Which wave integrates a packet, and when, never changes what it
+    // computes.  !PERSIST: the loop body runs once.
+    for (;;) {
+    // PERSIST: what is read at the start of a packet comes from the kernel-argument segment through a pointer the
+    // compiler cannot trace back (as in the service phase and the epilogue): as ordinary arguments these values would
+    // be live across the step loop of the packet before
+    const char __attribute__((address_space(4))) * kq_p =
+        (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+    if (PERSIST) asm volatile("" : "+s"(kq_p));
+    const FanArgs __attribute__((address_space(4))) & aq = *(const FanArgs __attribute__((address_space(4))) *)(kq_p + kFanArgsKernargOffset);
+    int* const wave_queue = PERSIST ? aq.wave_queue : nullptr;
+    const int* const q_map = PERSIST ? aq.wave_map : a.wave_map;
+    const int64_t q_N = PERSIST ? aq.N : a.N, q_stride_ray = PERSIST ? aq.stride_ray : a.stride_ray;
+    const double* const q_y0 = PERSIST ? aq.y0 : a.y0;
+    const uint32_t q_flags = PERSIST ? aq.flags : a.flags;
     // waves are dealt to workgroups round-robin (wave w of block b = global wave w*grid + b):
     // neighbouring launch angles cost alike, so a strided deal balances the CUs
     int64_t gwave = (int64_t)wv * gridDim.x + blockIdx.x;
-    if (a.wave_map) {
+    if (q_map) {
         // cost-aware scheduling (pgr_wave_place): slot -> wave (-1 = slot left empty) and the
         // wave's issue priority in bits 28..29: the costlier wave of a SIMD's pair runs at its own
         // pace, the cheaper one fills the issue slots it leaves
-        int m = a.wave_map[blockIdx.x * n_cw + wv];
+        int slot = blockIdx.x * n_cw + wv;
+        if (PERSIST && wave_queue) {
+            int got = 0;
+            if ((threadIdx.x & 63) == 0) got = atomicAdd(wave_queue, 1);
+            slot = __builtin_amdgcn_readfirstlane(got);
+            if (slot >= aq.n_queue) break;      // (wave-uniform: the list is empty, this wave is done)
+        }
+        int m = q_map[slot];
         gwave = (m < 0) ? -1 : (m & 0x0fffffff);
         int prio = __builtin_amdgcn_readfirstlane((m < 0) ? 0 : ((m >> 28) & 3));
         if (prio == 3) __builtin_amdgcn_s_setprio(3);
         else if (prio == 2) __builtin_amdgcn_s_setprio(2);
         else if (prio == 1) __builtin_amdgcn_s_setprio(1);
+        else if (PERSIST) __builtin_amdgcn_s_setprio(0);
     }
+    if (PERSIST) C.reset_range_cache();   // (a new packet starts at x0 again)
+#ifdef PGR_WAVE_TIMES   // (diagnostic build, scripts/wave_times.py: when and where every packet ran -- 100 MHz s_memrealtime stamps)
+    const unsigned wt_start = (unsigned)__builtin_amdgcn_s_memrealtime();
+#endif
     const int64_t ray = gwave * 64 + (threadIdx.x & 63);
-    const bool valid = (gwave >= 0) && (ray < a.N);
+    const bool valid = (gwave >= 0) && (ray < q_N);
     double SAFETY = 0.9, MIN_FACTOR = 0.2, MAX_FACTOR = 10,
            SQRT3 = 1.7320508075688772, INV_SQRT3 = 0.57735026918962584,
            POW_FIFTH = 0.2, POW_KLN2 = PGR_CR_POW_KLN2;
@@ -95,14 +129,14 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
 
     double t = a.x0, y0 = 0, y1 = 0, y2 = 0;
     if (valid) {
-        y0 = a.y0[3 * ray + 0];
-        y1 = a.y0[3 * ray + 1];
-        y2 = a.y0[3 * ray + 2];
+        y0 = q_y0[3 * ray + 0];
+        y1 = q_y0[3 * ray + 1];
+        y2 = q_y0[3 * ray + 2];
     }
     double f0 = 0, f1 = 0, f2 = 0, h_abs = 0;
     unsigned g = 0;
     int status = valid ? RUNNING : PGR_RAY_OK;
-    if (valid && (a.flags & PGR_SKIP_NAN_Y0) && (y2 != y2)) status = PGR_RAY_SKIPPED;  // a parked eigenray bracket
+    if (valid && (q_flags & PGR_SKIP_NAN_Y0) && (y2 != y2)) status = PGR_RAY_SKIPPED;  // a parked eigenray bracket
     bool need_init = true, rejected = false, parked = false;
     int nb = 0, ns = 0, n_steps = 0, n_rej = 0;
     int jnext = 0;
@@ -122,7 +156,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     for (int k = 0; k < 24; k++) tacc[k] = 0;
     unsigned tprev = (unsigned)clock64();
 #endif
-    const int64_t out_off = ray * a.stride_ray;
+    const int64_t out_off = ray * q_stride_ray;
 #define Tp (a.T + out_off)
 #define Zp (a.Z + out_off)
 #define Pp (a.P + out_off)
@@ -853,11 +887,24 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
             n_rej = (int)v;
         }
 #endif
+#ifdef PGR_WAVE_TIMES
+        if (a.flags & PGR_DEBUG_TRIPS) {
+            const int ln = (int)(threadIdx.x & 63);
+            const unsigned wt_end = (unsigned)__builtin_amdgcn_s_memrealtime();
+            const unsigned hw_id = __builtin_amdgcn_s_getreg((4 /* HW_REG_HW_ID */) | (0 << 6) | (31 << 11));
+            const unsigned xcc_id = __builtin_amdgcn_s_getreg((20 /* HW_REG_XCC_ID */) | (0 << 6) | (31 << 11));
+            fallbacks = ln == 3 ? (int)wt_start : ln == 4 ? (int)wt_end : ln == 5 ? (int)hw_id : ln == 6 ? (int)xcc_id
+                        : ln == 7 ? (int)blockIdx.x : fallbacks;
+        }
+#endif
         if (a.n_rej) a.n_rej[ray] = (a.flags & PGR_DEBUG_TRIPS) ? (((threadIdx.x & 63) == 0) ? trips : (((threadIdx.x & 63) == 1) ? services : fallbacks)) : n_rej;
     }
+    if (!PERSIST || !wave_queue) break;   // (a persistent instance launched without a queue is one packet per wave too)
+    }   // (the packet loop)
 #undef Tp
 #undef Zp
 #undef Pp
+#undef SGN
 }
 
 #endif  // PGR_FAN_KERNEL_H

@@ -39,8 +39,15 @@ def _regula_falsi_batch(z1, z2, th1, th2, receiver_depth, source_depth, source_r
     env, (cin, rin, zin) = _device_env(environment, flatearth, backwards, device)
     x0, x1 = (-source_range, -receiver_range) if backwards else (source_range, receiver_range)
     c0 = bilinear_interp(x0, source_depth, rin, zin, cin)            # REF/launch_rays.py:284
+    # ONE arithmetic for every initial slowness, the reference's: NumPy's sin(radians(.)) / c (REF/launch_rays.py:284-285)
+    # -- for the fan (launch_rays._initial_slowness), for the trial rays of the device loop (handed in as a callback: the
+    # loop sends the active brackets' angles down once per iteration) and for the eigenrays re-shot below.  So
+    # shoot_ray(theta) of an eigenray's angle starts from the same bits as the eigenray itself.
+    from .launch_rays import _initial_slowness
     out = env.eigen_refine(th1, th2, z1, z2, rd_k, source_depth, x0, x1, c0, rtol=rtol,
-                           terminate_backwards=terminate_backwards, ztol=ztol, max_iter=max_iter)
+                           terminate_backwards=terminate_backwards, ztol=ztol, max_iter=max_iter,
+                           slowness=lambda ang: _initial_slowness(ang, c0))
+    LAST_SEARCH_STATS.setdefault("reshot_differs", 0)
     LAST_SEARCH_STATS["launches"] = LAST_SEARCH_STATS.get("launches", 0) + out["launches"]
     LAST_SEARCH_STATS["trial_rays"] = LAST_SEARCH_STATS.get("trial_rays", 0) + int(out["n_trial"].sum())
     if not quiet:
@@ -56,15 +63,15 @@ def _regula_falsi_batch(z1, z2, th1, th2, receiver_depth, source_depth, source_r
     if found.any():
         idx = np.where(found)[0]
         # the eigenrays themselves, with trajectories: shoot_ray(theta), ODE angle = -theta (REF/launch_rays.py:251), from
-        # the SAME initial state as the trial ray the search accepted -- computed on the device from the angle with the
-        # correctly rounded sine, as pgr_eigen_step did -- so the ray returned IS the accepted one
+        # the SAME initial state as the trial ray the search accepted -- NumPy's sin(radians(.)) / c, as the callback
+        # above computed it -- so the ray returned IS the accepted one
         from .launch_rays import _launch_device_fan
         # (one ray per wave while they fit one wave per SIMD: the eigenrays of different brackets bounce at different ranges)
         # -- and while the padding stays small: the launch owns 3 * N * S * 8 B of HBM for N = spread * len(idx) rays and
         # the compact fetch sizes its host buffers alike (1000 eigenrays x S = 1001 would be 1.5 GB of each for 24 MB of data)
         spread = 64 if (len(idx) <= 1024 and len(idx) * 64 * S * 24 <= 256 * 1024 * 1024) else 1
         h, r = _launch_device_fan(source_depth, source_range, -th_found[idx], receiver_range, S, environment, rtol,
-                                  terminate_backwards, flatearth, device=device, stored_sign=True, device_y0=True, spread=spread)
+                                  terminate_backwards, flatearth, device=device, stored_sign=True, spread=spread)
         LAST_SEARCH_STATS["launches"] += 1
         rays = {k: v[::spread] for k, v in h.fetch_rays().items()}
         if not np.all(rays["status"] == 0):
@@ -75,12 +82,16 @@ def _regula_falsi_batch(z1, z2, th1, th2, receiver_depth, source_depth, source_r
             raise RuntimeError("find_eigenrays: a re-shot eigenray differs from the trial ray the search accepted")
         # (the ztol check above is the guard the user relies on.  That the re-shot ray -- trajectory kernel -- ends on the SAME
         # BITS as the accepted trial ray -- end-state kernel -- is a property of the build that tests assert
-        # (tests/test_hip_parity.py, PGR_EIGEN_STRICT=1); a one-ulp divergence between two kernel instances must not fail
-        # a whole search: the affected brackets are recorded instead)
+        # (PGR_EIGEN_STRICT=1, set for the whole test suite by tests/conftest.py); a one-ulp divergence between two kernel
+        # instances must not fail a user's whole search: the affected brackets are recorded and a warning is raised instead)
         differs = -rays["end"][:, 1] != out["z_end"][idx]
         LAST_SEARCH_STATS["reshot_differs"] = LAST_SEARCH_STATS.get("reshot_differs", 0) + int(differs.sum())
-        if differs.any() and os.environ.get("PGR_EIGEN_STRICT") == "1":
-            raise RuntimeError("find_eigenrays: a re-shot eigenray does not end where its trial ray did")
+        if differs.any():
+            if os.environ.get("PGR_EIGEN_STRICT") == "1":     # (tests/conftest.py sets it for the whole suite)
+                raise RuntimeError("find_eigenrays: a re-shot eigenray does not end where its trial ray did")
+            import warnings
+            warnings.warn(f"find_eigenrays: {int(differs.sum())} re-shot eigenray(s) end within ztol but not on the bits of "
+                          "the trial ray the search accepted (two kernel instances diverged)", RuntimeWarning)
         T[idx], Z[idx], P[idx] = smp["T"].T, smp["z"].T, smp["p"].T
         nb[idx], ns[idx] = rays["n_bott"], rays["n_surf"]
     return found, th_found, r, T, Z, P, nb, ns

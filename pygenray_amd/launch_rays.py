@@ -100,8 +100,9 @@ def _launch_device_fan(source_depth, source_range, ode_angles_deg, receiver_rang
                        terminate_backwards, flatearth, device=0, max_steps=1_000_000, stored_sign=True,
                        device_y0=False, spread=1):
     """The fan of _shoot_ode_angles launched device-resident (``_lib.FanHandle``): returns (handle, r) while the kernel
-    runs.  ``device_y0``: the initial states are computed on the device from the angles (correctly rounded sine: what
-    the eigenray refinement's trial rays use) instead of uploaded.  ``spread`` (with device_y0): ray k of the caller is
+    runs.  ``device_y0``: the initial states are computed on the device from the angles (correctly rounded sine) instead of
+    from NumPy's sin(radians(.)) / c on the host (the default, the reference's arithmetic: fans, eigenray trial rays and the
+    eigenrays handed back all use it).  ``spread``: ray k of the caller is
     ray k * spread of the launch, the rays between are padding that is never integrated (status 8) -- unrelated rays
     (the eigenrays of different brackets) get a wave each instead of bouncing in each other's way."""
     backwards = receiver_range < source_range
@@ -120,7 +121,12 @@ def _launch_device_fan(source_depth, source_range, ode_angles_deg, receiver_rang
         h = _lib.FanHandle(env, x0, x1, num_range_save, ode_angles_deg=ang, source_depth=source_depth, c_source=c, **kw)
     else:
         # NumPy's own sin(radians(.)) / c, as the reference computes it; [0, z_s, p0] is assembled on the device
-        h = _lib.FanHandle(env, x0, x1, num_range_save, p0=_initial_slowness(ang, c), source_depth=source_depth, **kw)
+        p0 = _initial_slowness(ang, c)
+        if spread > 1:
+            padded = np.full(len(p0) * int(spread), np.nan)
+            padded[::int(spread)] = p0
+            p0, kw = padded, dict(kw, skip_nan=True)
+        h = _lib.FanHandle(env, x0, x1, num_range_save, p0=p0, source_depth=source_depth, **kw)
     r = np.linspace(x0, x1, int(num_range_save))
     return h, (-r if backwards else r)
 

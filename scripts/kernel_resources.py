@@ -8,6 +8,6 @@ for blk in md.split("  - .agpr_count:")[1:]:
     if "fan_kernel" not in name:
         continue
     g = lambda k: re.search(r"\.%s:\s+(\d+)" % k, blk).group(1)
-    m = re.search(r"ILb(\d)ELi(\d)ELi(\d)E", name)
-    print("LT %s ZM %s SAVE %s" % m.groups(), "vgpr", g("vgpr_count"), "sgpr", g("sgpr_count"), "scratch", g("private_segment_fixed_size"),
+    m = re.search(r"ILb(\d)ELi(\d)ELi(\d)ELb(\d)E", name)
+    print("LT %s ZM %s SAVE %s PERSIST %s" % m.groups(), "vgpr", g("vgpr_count"), "sgpr", g("sgpr_count"), "scratch", g("private_segment_fixed_size"),
           "sgpr spills", g("sgpr_spill_count"), "vgpr spills", g("vgpr_spill_count"))
