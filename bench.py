@@ -256,7 +256,8 @@ def extra_legs():
     _, arrs1 = munk_tables(RANGE_M)
     legs["rays_1e6"] = {
         "workload": "configs[1] tables, 1e6 launch angles (the per-GPU fan of configs[3] / configs[4]), end state only",
-        "kernel": "pgr_fan_kernel<true, 4, 0>", "end_state": kernel_leg(arrs1, 1_000_000, False, passes=3)}
+        "kernel": "pgr_fan_kernel<true, 4, 0, true> (persistent waves: one workgroup per CU, 64-ray packets claimed from the cost-sorted list)",
+        "end_state": kernel_leg(arrs1, 1_000_000, False, passes=3)}
     lone = {"end_state": kernel_leg(arrs1, RAYS_PER_GPU, False, rays_lo=(0, 64)),
             "trajectories": kernel_leg(arrs1, RAYS_PER_GPU, True, rays_lo=(0, 64))}
     return legs, lone
@@ -281,9 +282,13 @@ def config4_leg(env, arrs, rank, world, fence, passes=3, rays_per_gpu=1_000_000,
     t_lo, t_hi = RANGE_M / 1560.0, RANGE_M / 1400.0
     hist, gathered = None, None
 
+    kev = []
+
     def one_pass(pending):
         nonlocal hist, gathered
-        fan.run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fan.run(); e1.record()
+        kev.append((e0, e1))
         hist = arrival_time_histogram(fan.records[:fan.N, 0], fan.status, bins, t_lo, t_hi, reduce=True)
         started = start_all_gather_records(fan.records, n_global)
         if pending is not None:
@@ -293,6 +298,7 @@ def config4_leg(env, arrs, rank, world, fence, passes=3, rays_per_gpu=1_000_000,
     pending = one_pass(None)
     pending.finish()
     fence()
+    kev.clear()
     t0 = time.perf_counter()
     pending = None
     for _ in range(passes):
@@ -306,7 +312,18 @@ def config4_leg(env, arrs, rank, world, fence, passes=3, rays_per_gpu=1_000_000,
     dist.all_reduce(ss, op=dist.ReduceOp.SUM)
     end_all, _, _, st_all = gathered
     ok_all = int((st_all == 0).sum().item())
-    return {"workload": f"configs[4]: {n_global} launch angles linspace(-20, 20) over {world} ranks ({rays_per_gpu} per GPU, strided), "
+    # per GPU: the fan kernel's own time (HIP events on the launch stream, this rank's passes) and the fraction of the HBM
+    # peak its algorithmic bytes (80 B per ray-step, end state only) amount to -- gathered, so that the line is gradeable
+    # per GPU whatever the collectives cost
+    kms = float(np.mean([a.elapsed_time(b) for a, b in kev]))
+    mine = torch.tensor([kms, float(fan.ray_steps())], dtype=torch.float64, device="cuda")
+    per = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(per, mine)
+    per_gpu = [{"rank": k, "kernel_ms": float(p_[0].item()), "ray_steps": int(p_[1].item()),
+                "frac": float(p_[1].item()) * 80.0 / (float(p_[0].item()) * 1e-3) / 1e9 / HBM_PEAK_GBS} for k, p_ in enumerate(per)]
+    return {"roofline_per_gpu": {"bound": "hbm", "bytes_per_ray_step": 80.0, "peak_gbs": HBM_PEAK_GBS,
+                                 "kernel": "pgr_fan_kernel<true, 4, 0, true> (persistent waves)", "ranks": per_gpu,
+                                 "frac_min": min(q["frac"] for q in per_gpu), "kernel_ms_max": max(q["kernel_ms"] for q in per_gpu)},"workload": f"configs[4]: {n_global} launch angles linspace(-20, 20) over {world} ranks ({rays_per_gpu} per GPU, strided), "
                         "1000 km, end state only; per pass: fan kernel (40-byte end records written in place), 4096-bin arrival-time "
                         "histogram + all-reduce, all-gather of the end records (overlapping the next pass)",
             "ms_per_pass": float(tt.item()) / passes * 1e3, "passes": passes,
@@ -316,8 +333,8 @@ def config4_leg(env, arrs, rank, world, fence, passes=3, rays_per_gpu=1_000_000,
             "all_gather_bytes_per_rank": n_pad * 40, "ranks": world}
 
 
-def api_leg(env_obj, calls=3):
-    """What a `pr.shoot_rays` caller sees on configs[1] (1e5 launch angles, 1000 km, S = 1001): wall clock of the drop-in
+def api_leg(env_obj, calls=3, what="configs[1]"):
+    """What a `pr.shoot_rays` caller sees on configs[1] / configs[2] (1e5 launch angles, 1000 km, S = 1001): wall clock of the drop-in
     call itself -- environment unpack, initial states, kernel, compaction of dropped rays, PCIe, RayFan -- eager
     (`device_resident=False`: all three (M, S) arrays on the host when the call returns) and device resident (the
     default for a fan this size: per-ray arrays and end states on the host, trajectories fetched when first read),
@@ -327,7 +344,7 @@ def api_leg(env_obj, calls=3):
     angles = np.linspace(-20, 20, RAYS_PER_GPU)
     kw = dict(debug=False, flatearth=False)
     pr.shoot_rays(SOURCE_DEPTH, 0.0, angles[:1000], RANGE_M, S_SAVE, env_obj, **kw)      # table upload, library warm-up
-    out = {"workload": "pr.shoot_rays(1000 m, 0, linspace(-20, 20, 100000), 1000 km, 1001, env, flatearth=False): configs[1] through the drop-in API",
+    out = {"workload": f"pr.shoot_rays(1000 m, 0, linspace(-20, 20, 100000), 1000 km, 1001, env, flatearth=False): {what} through the drop-in API",
            "calls": calls}
     for name, mode in (("eager", False), ("device_resident", True)):
         walls, reads = [], []
@@ -550,7 +567,11 @@ def main(argv=None):
             t_c = time.perf_counter()
         tt = torch.tensor([t_c - t_a, t_b - t_a], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        # per GPU: this rank's share of the fan (rays, accepted steps are not returned by the end-record path: the share of the
+        # 1e6-angle fan is N / world rays) against the wall time of the sharded fan call (kernel + all-gather + host)
+        share = len(shard_indices(args.eigen_rays, rank, world))
         eig_sharded = {"wall_s": float(tt[0].item()), "fan_s": float(tt[1].item()), "fan_rays": int(args.eigen_rays),
+                       "fan_rays_per_gpu": int(share), "fan_rays_per_s_per_gpu": share / float(tt[1].item()),
                        "ranks": world, "brackets": int(ger.num_eigenrays[1000.0]), "found": int(ger.num_eigenrays_found[0]),
                        "failed": len(ger.failed_eray_theta_brackets[0]),
                        "config": "configs[3] sharded: pygenray_amd.distributed.shoot_rays_sharded (strided shards, all-gather "
@@ -581,7 +602,8 @@ def main(argv=None):
             try:
                 tj = json.load(open(tpath))
                 key = (("rangedep-" if args.range_dependent else "") + ("flatearth-" if args.flat_earth else "")
-                       + ("blocked" if (args.blocked and save) else args.layout) + ("" if save else "-nosave"))
+                       + ("blocked" if (args.blocked and save) else args.layout) + ("" if save else "-nosave")
+                       + ("" if fan.N == RAYS_PER_GPU else f"@{fan.N}"))
                 if key not in tj or tj[key].get("rays") != fan.N:
                     tnote = f"profiles/{tfiles[-1]} holds no PMC pass of this workload"
                 elif tj.get("device_code_sha256") != code_sha:
@@ -621,7 +643,8 @@ def main(argv=None):
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_gb_per_launch": traffic_gb, "traffic_source": tnote,
                          "algorithmic_gb_per_launch": local_steps * b_alg / 1e9,
-                         "kernel": f"pgr_fan_kernel<{'false' if args.range_dependent else 'true'}, {5 if args.flat_earth else 4}, {(3 if args.blocked else 1) if save else 0}> "
+                         "kernel": f"pgr_fan_kernel<{'false' if args.range_dependent else 'true'}, {5 if args.flat_earth else 4}, {(3 if args.blocked else 1) if save else 0}, "
+                                   f"{'true' if (fan.N + 63) // 64 > 8 * 256 else 'false'}> "
                                    f"(table in {'HBM/L2' if args.range_dependent else 'LDS'}, "
                                    f"{'non-uniform zin, cubic index estimate' if args.flat_earth else 'zin = j * 1 m'}, "
                                    f"{'linspace save grid' if save else 'end state only'})", "kernel_ms": kern_ms,
@@ -654,6 +677,10 @@ def main(argv=None):
             del fan   # (2.4 GB of trajectories back before the legs allocate theirs)
             legs, lone = extra_legs()
             legs["api"] = api_leg(env_obj)
+            # configs[2] through the same API: the tables stay in HBM / L2, so the fan runs the sample-blocked kernel
+            # <false, 4, 3> and is un-blocked by the pass that squeezes its dropped rays out (PGR_OPT_API_BLOCKED)
+            env_rd, _ = munk_tables(RANGE_M, nr=101, sofar_slope=2e-4)
+            legs["api_config2"] = api_leg(env_rd, what="configs[2] (range-dependent tables: sample-blocked kernel, un-blocked on the way out)")
             out["legs"] = legs
             # the fan cannot finish before its steepest rays do: the first wave of the fan (64 steepest rays) ALONE
             out["lone_wave_ms"] = {"end_state": lone["end_state"]["kernel_ms"], "trajectories": lone["trajectories"]["kernel_ms"],

@@ -258,12 +258,18 @@ int pgr_arrival_histogram_device(int device, const double* t_end, int64_t t_stri
  *                            one workgroup per CU whose waves claim packet after packet from the cost-sorted list
  *                            (most expensive first) with one atomic each; a = 0 the static deal of whole
  *                            cost-sorted workgroups (what replaces the reference's pool.imap over single rays,
- *                            REF/launch_rays.py:157-164, either way) */
+ *                            REF/launch_rays.py:157-164, either way)
+ *   PGR_OPT_API_BLOCKED      pgr_shoot_fan (sample-major) and pgr_fan_launch on environments whose tables stay in HBM / L2:
+ *                            a = 1 (default) the trajectories are integrated by the sample-blocked kernel
+ *                            (PGR_SAMPLE_BLOCKED: full 32-byte stores, 1.2x instead of 2.3x the sample bytes written) and
+ *                            un-blocked to [S][M] by the pass that squeezes dropped rays out on the way to the host;
+ *                            a = 0 plain [S][N] rows.  The caller sees the same arrays, bit for bit. */
 #define PGR_OPT_WAVES_PER_BLOCK 0
 #define PGR_OPT_DEPTH_SEARCH 1
 #define PGR_OPT_PARK 2
 #define PGR_OPT_PLACEMENT 3
 #define PGR_OPT_PERSISTENT 4
+#define PGR_OPT_API_BLOCKED 5
 int pgr_env_set_option(pgr_env* env, int what, int a, int b);
 
 /* Unit-level device entry points (for parity tests of a1-a8, REF/integration_processes.py):

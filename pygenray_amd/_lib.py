@@ -256,7 +256,7 @@ class EnvHandle:
         return load().pgr_env_query(self._h, int(what))
 
     # tuning options of this environment (include/pgr.h; results never depend on them)
-    _OPTIONS = {"waves_per_block": 0, "depth_search": 1, "park": 2, "placement": 3, "persistent": 4}
+    _OPTIONS = {"waves_per_block": 0, "depth_search": 1, "park": 2, "placement": 3, "persistent": 4, "api_blocked": 5}
 
     def set_option(self, name, a, b=0):
         check(load().pgr_env_set_option(self._h, self._OPTIONS[name], int(a), int(b)))

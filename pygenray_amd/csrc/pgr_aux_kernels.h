@@ -119,7 +119,7 @@ __global__ void pgr_step_kernel(const EnvDev* __restrict__ env_p, const double* 
     const double t = tt[k], h = hh[k], y0 = yy[3 * k], y1 = yy[3 * k + 1], y2 = yy[3 * k + 2];
     double f0, f1, f2, c0;
     C.rhs(t, y1, y2, f0, f1, f2, c0);
-#ifdef PGR_TIMING
+#if defined(PGR_TIMING) || defined(PGR_SVC_TIMING)
     unsigned tacc[24] = {0}, tprev = 0;  // (the stage macro's stamps)
 #endif
     PGR_RK_STAGES(t, h);

@@ -844,8 +844,8 @@ struct Dense {
 #define PGR_SB() __builtin_amdgcn_sched_barrier(0)
 // -DPGR_TIMING (experiments only): s_memtime stamps along one step attempt; the time between stamp
 // k-1 and stamp k accumulates in tacc[k] and comes back in n_rej[] of lanes 0..23 (scripts/phase_times.py)
-#ifdef PGR_TIMING
-#define PGR_STAMP(k)                                                                                 \
+#if defined(PGR_TIMING) || defined(PGR_SVC_TIMING)
+#define PGR_STAMP_(k)                                                                                 \
     do {                                                                                             \
         unsigned long long _t;                                                                       \
         PGR_SB();                                                                                    \
@@ -854,8 +854,18 @@ struct Dense {
         tprev = (unsigned)_t;                                                                        \
         PGR_SB();                                                                                    \
     } while (0)
+#endif
+// -DPGR_TIMING: the stamps of the step attempt; -DPGR_SVC_TIMING: the stamps of the bounce SERVICE phase instead (tacc[23]
+// collects everything outside it), scripts/service_times.py
+#ifdef PGR_TIMING
+#define PGR_STAMP(k) PGR_STAMP_(k)
 #else
 #define PGR_STAMP(k) do { } while (0)
+#endif
+#ifdef PGR_SVC_TIMING
+#define PGR_SSTAMP(k) PGR_STAMP_(k)
+#else
+#define PGR_SSTAMP(k) do { } while (0)
 #endif
 // ZM == 5: the arithmetic half of a look-up starts with a (rarely taken) branch, and the compiler sinks the
 // independent sums placed in the read's shadow below it -- the wave would then wait for the LDS with nothing to

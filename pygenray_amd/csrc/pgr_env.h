@@ -25,6 +25,10 @@ extern "C" int pgr_env_set_option(pgr_env* env, int what, int a, int b)
         if (a < 0 || a > 2) return fail("placement: 0 = off, 1 = priorities only, 2 = placement + priorities");
         env->place = a;
         return 0;
+    case PGR_OPT_API_BLOCKED:
+        if (a < 0 || a > 1) return fail("api_blocked: 0 = row layout, 1 = sample-blocked kernel for HBM-table trajectory fans of pgr_shoot_fan / pgr_fan_launch");
+        env->api_blocked = a;
+        return 0;
     case PGR_OPT_PERSISTENT:
         if (a < 0 || a > 1) return fail("persistent: 0 = static deal of whole workgroups, 1 = persistent waves + packet queue");
         env->persistent = a;

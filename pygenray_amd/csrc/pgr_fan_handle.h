@@ -53,6 +53,7 @@ struct pgr_fan {
     int32_t S = 0;
     uint32_t flags = 0;
     bool save = false, finished = false;
+    bool blocked = false;   // T / Z / P are held sample-blocked, [ceil(S/4)][N][4] (PGR_SAMPLE_BLOCKED): every fetch un-blocks
     void* buf = nullptr;
     size_t buf_bytes = 0;
     double *y0 = nullptr, *r = nullptr, *T = nullptr, *Z = nullptr, *P = nullptr, *end = nullptr;
@@ -109,7 +110,10 @@ extern "C" int pgr_fan_launch(pgr_env* env, const double* y0, const double* ode_
     }
     f->flags = (flags & ~(uint32_t)(PGR_COMPACT | PGR_PACKED_END | PGR_LAUNCH_SLOWNESS)) | PGR_SAMPLE_MAJOR | PGR_SAVE_LINSPACE;
     f->stream = env->stream;
-    const size_t ns_bytes = (size_t)N * (size_t)S * sizeof(double);
+    // environments whose tables stay in HBM / L2: the sample-blocked kernel, un-blocked when the samples are fetched
+    f->blocked = f->save && !(flags & PGR_EXACT_SAMPLES) && blocked_layout_fits(env);
+    if (f->blocked) f->flags |= PGR_SAMPLE_BLOCKED;
+    const size_t ns_bytes = (size_t)N * (size_t)(f->blocked ? 4 * ((S + 3) / 4) : S) * sizeof(double);
     const size_t sizes[11] = {(size_t)N * 24, (size_t)(S > 0 ? S : 1) * 8, ns_bytes, ns_bytes, ns_bytes, (size_t)N * 24,
                               (size_t)N * 4, (size_t)N * 4, (size_t)N * 4, (size_t)N * 4, (size_t)N * 4};
     size_t off[11], total = 0;
@@ -278,7 +282,7 @@ extern "C" int pgr_fan_fetch_samples(pgr_fan* f, double* T, double* z, double* p
     std::lock_guard<std::mutex> lock(f->m);
     HIPCHK(hipSetDevice(f->env->device));
     const bool compact = (flags & PGR_COMPACT) != 0;
-    const size_t ns_bytes = (size_t)f->N * (size_t)f->S * sizeof(double);
+    const size_t ns_bytes = (size_t)f->N * (size_t)f->S * sizeof(double);   // (what reaches the caller: [S][N], or less)
     std::vector<D2HJob> jobs;
     std::vector<const double*> src;
     if (T) { jobs.push_back({T, f->T, ns_bytes}); src.push_back(f->T); }
@@ -290,20 +294,27 @@ extern "C" int pgr_fan_fetch_samples(pgr_fan* f, double* T, double* z, double* p
     auto ready = [&](std::vector<D2HJob>& jb) -> int {
         int rc = fan_finish(f);
         if (rc) return rc;
-        if (!compact || f->M == f->N) return 0;
-        const int64_t M = f->M;
+        const bool squeeze = compact && f->M != f->N;
+        if (!squeeze && !f->blocked) return 0;
+        const int64_t M = squeeze ? f->M : f->N;
         const size_t mbytes = (size_t)f->S * (size_t)M * sizeof(double);
         if (M > 0) {
             void* didx = nullptr;
-            HIPCHK(hipMalloc(&didx, (size_t)M * sizeof(int)));
-            tmp.p.push_back(didx);
-            HIPCHK(hipMemcpyAsync(didx, f->keep.data(), (size_t)M * sizeof(int), hipMemcpyHostToDevice, st));
+            if (squeeze) {
+                HIPCHK(hipMalloc(&didx, (size_t)M * sizeof(int)));
+                tmp.p.push_back(didx);
+                HIPCHK(hipMemcpyAsync(didx, f->keep.data(), (size_t)M * sizeof(int), hipMemcpyHostToDevice, st));
+            }
             for (size_t a3 = 0; a3 < jb.size(); a3++) {
                 void* t = nullptr;
                 HIPCHK(hipMalloc(&t, mbytes));
                 tmp.p.push_back(t);
-                hipLaunchKernelGGL(pgr_gather_cols, dim3((unsigned)((M + 255) / 256), (unsigned)f->S), dim3(256), 0, st,
-                                   (const double*)jb[a3].src, (double*)t, (const int*)didx, M, f->N);
+                if (f->blocked)
+                    hipLaunchKernelGGL(pgr_unblock_cols, dim3((unsigned)((M + 255) / 256), (unsigned)((f->S + 3) / 4)), dim3(256), 0, st,
+                                       (const double*)jb[a3].src, (double*)t, (const int*)didx, M, f->N, (int)f->S);
+                else
+                    hipLaunchKernelGGL(pgr_gather_cols, dim3((unsigned)((M + 255) / 256), (unsigned)f->S), dim3(256), 0, st,
+                                       (const double*)jb[a3].src, (double*)t, (const int*)didx, M, f->N);
                 HIPCHK(hipGetLastError());
                 jb[a3].src = t;
             }

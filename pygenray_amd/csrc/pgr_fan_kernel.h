@@ -151,7 +151,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     const double min_step_bound = 10 * 0x1p-52 * fmax(fabs(a.x0), fabs(a.x1)) + 1e-300;  // see the attempt's head
     const int max_steps32 = (int)(a.max_steps < 0x7fffffff ? a.max_steps : 0x7fffffff);  // n_steps is an int
     const int guard_limit = (max_steps32 < attempt_limit ? max_steps32 : attempt_limit);
-#ifdef PGR_TIMING
+#if defined(PGR_TIMING) || defined(PGR_SVC_TIMING)
     unsigned tacc[24];
     for (int k = 0; k < 24; k++) tacc[k] = 0;
     unsigned tprev = (unsigned)clock64();
@@ -461,6 +461,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
             if (__popcll(pm) >= a.park_lanes || waited > a.park_trips || nobody_steps) {
                 waited = 0;
                 services++;
+                PGR_SSTAMP(23);   // (everything since the last service)
                 // =========================== SERVICE phase ===========================
                 // what only the service needs of the environment descriptor and of the kernel arguments is read
                 // HERE, through pointers the compiler cannot trace back (the empty asm): hoisted to the prologue
@@ -479,6 +480,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                     // the parked attempt: same t, y, f and h = t_new - t as when it ran
                     const double t_new = pk_tnew, h = t_new - t;
                     Dense D;
+                    PGR_SSTAMP(0);    // descriptor / argument loads, entry
                     if (KEEPK) {
                         PGR_FORM_Q();          // from the stage values the parked attempt left in this lane's registers
                     } else {
@@ -487,6 +489,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                         (void)n0; (void)c_new; (void)es0; (void)es1; (void)es2;
                         PGR_FORM_Q();
                     }
+                    PGR_SSTAMP(1);    // Q
                     int ev = -1;
                     double best = 0;
                     // (a step that crosses the surface nearly always also crosses the bounding box's
@@ -524,6 +527,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                         // only has to land inside the noise band, checked at its edges below) takes that instead of
                         // a look-up per iterate
                         const bool chord = ballot64(bottom && cell_s != cell_e) == 0;
+                        PGR_SSTAMP(2);    // bracket values, bathymetry at the step's ends
                         if (pre) {
                             const double bslope = bottom ? (be - bs) : 0.0;  // per unit s
                             double lo = 0.0, hi = 1.0;
@@ -554,6 +558,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                                 sN = sn;
                                 if (it >= 2 && ballot64(ds * h >= 1e-12 * (1.0 + fabs(t))) == 0) break;
                             }
+                            PGR_SSTAMP(3);    // Newton
                             const double xs = t + sN * h;
                             // E: rounding noise of F as the event evaluates it.  z(x) = h (Q p) + y_old: half an ulp
                             // of the result for the last add and ~4 roundings of terms <= |h| sum|Q|; the sea floor
@@ -595,6 +600,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                             // with the bounding-box event also active its flip must lie beyond xb, so
                             // that the surface root is the earlier one (SCIPY/ivp.py:100-131)
                             live = (xa < xb) && !ga && gb && !(with_bbox && bbox_b);
+                            PGR_SSTAMP(4);    // band + the true event at its two edges
 #ifndef PGR_NO_BAND_TABLE
                             // The doubles strictly inside the band: one or two once the noise band is narrower than
                             // an ulp of x (beyond ~100 km).  Evaluate the true event there as well, and if it flips
@@ -618,19 +624,20 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                                 }
                             }
 #endif
+                            PGR_SSTAMP(5);    // the doubles inside a narrow band
                         }
 #ifdef PGR_NO_REPLAY  // experiments: round 1's "a root within brentq's tolerance" (NOT bit-identical)
                         if (live) { best = xb; ev = bottom ? 1 : 0; }
 #else
-                        // ---- the replay.  brentq's state: cur = the latest iterate, blk = the other end of
-                        // the bracket, fcur = the event at cur; it starts from cur = t_new (fired), blk = t.
+                        // ---- the replay.  brentq's state: cur = the latest iterate, xblk = the other end of
+                        // the bracket, fcur = the event at cur; it starts from cur = t_new (fired), xblk = t.
                         const double xtol = 4 * DBL_EPSILON, brtol = 4 * DBL_EPSILON;
-                        double cur = t_new, blk = t;
+                        double cur = t_new, xblk = t;
                         bool fcur = true;
                         {
                             // phase 1: the halvings that can neither end the search nor take brentq's minimum
-                            // step (|blk - cur| / 2 stays above 4 delta), kept as (not fired end, fired end): 9
-                            // instructions each, no tolerance arithmetic.  cur + (blk - cur) / 2 and lo + (hi -
+                            // step (|xblk - cur| / 2 stays above 4 delta), kept as (not fired end, fired end): 9
+                            // instructions each, no tolerance arithmetic.  cur + (xblk - cur) / 2 and lo + (hi -
                             // lo) / 2 are the same double when hi - lo is exact (ends within a factor of two of
                             // each other).  An iterate that falls inside the band moves neither end, so the lane
                             // stays where it is (the next round computes the same iterate again) and phase 2
@@ -656,8 +663,9 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                                 plo = le ? nw : plo;
                                 lastc = ge | (lastc & !le);
                             }
-                            if (n1 > 0) { cur = lastc ? phi : plo; blk = lastc ? plo : phi; fcur = lastc; }
+                            if (n1 > 0) { cur = lastc ? phi : plo; xblk = lastc ? plo : phi; fcur = lastc; }
                         }
+                        PGR_SSTAMP(6);    // replay phase 1
                         // phase 2: brentq's loop as it stands (scipy/optimize/Zeros/brentq.c) for the last few
                         // iterations, all lanes in lock step; the true event is evaluated (for the whole wave,
                         // behind a uniform branch) whenever some lane's iterate lies inside the band, and
@@ -666,7 +674,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                         bool done = !live;
                         for (int it = 0; it < 200; it++) {
                             const double dlt = (xtol + brtol * fabs(cur)) / 2;
-                            const double sbis = (blk - cur) / 2;
+                            const double sbis = (xblk - cur) / 2;
                             done = !live | (fabs(sbis) < dlt);
                             if (ballot64(!done) == 0) break;
                             const double nw = (fabs(sbis) > dlt) ? cur + sbis : cur + (sbis > 0 ? dlt : -dlt);
@@ -678,11 +686,12 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                                 (void)bbox_q;
                                 fnv = inside ? (fired ? 1.0 : 0.0) : fnv;
                             }
-                            blk = (!done & (fnv != fcv)) ? cur : blk;
+                            xblk = (!done & (fnv != fcv)) ? cur : xblk;
                             cur = done ? cur : nw;
                             fcv = done ? fcv : fnv;
                         }
                         if (live && done) { best = cur; ev = bottom ? 1 : 0; }
+                        PGR_SSTAMP(7);    // replay phase 2
 #endif
                     }
                     if (ev < 0) {
@@ -718,6 +727,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                             if (ev < 0 || xcur < best) { best = xcur; ev = k; }
                         }
                     }
+                    PGR_SSTAMP(8);    // (exact bisection, if any)
                     if (status == RUNNING) {
                         const double t_end = best;
                         // samples of this (truncated) step, REF/launch_rays.py:763-772 (Q5)
@@ -732,9 +742,11 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                         }
                         // terminal event: t = root, y = sol(root) (SCIPY/ivp.py:689-692), then the
                         // bounce logic of REF/launch_rays.py:432-480
+                        PGR_SSTAMP(9);    // samples of the truncated step
                         double r0, r1, r2;
                         D.eval(t, y0, y1, y2, t_end, r0, r1, r2);
                         t = t_end; y0 = r0; y1 = r1; y2 = r2;
+                        PGR_SSTAMP(10);   // state at the root
                         if (ev == 2) status = PGR_RAY_VERTICAL;
                         else if (ev == 3) status = PGR_RAY_BBOX;
                         else {
@@ -744,6 +756,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                             const PGR_ASIN_DD_T A_b = PGR_ASIN_DD(pc_b);
                             double theta = PGR_ASIN_DD_HI(A_b) * (180.0 / M_PI);  // ray_angle
                             double theta_b;
+                            PGR_SSTAMP(11);   // look-up + arcsine
                             if (ev == 0) {
                                 theta_b = -theta;
                                 ns++;
@@ -773,6 +786,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                                     nb++;
                                 }
                             }
+                            PGR_SSTAMP(12);   // reflection law (bottom: the angle's cubic)
                             if (status == RUNNING) {
                                 if ((as.flags & PGR_TERMINATE_BACKWARDS) && (fabs(theta_b) > 90))
                                     status = PGR_RAY_BACKWARD;
@@ -787,6 +801,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                         }
                     }
                 }
+                PGR_SSTAMP(13);   // new slowness (sine), end of the bounce block
                 if (status == RUNNING && need_init) {
                     // ---- fresh solve_ivp: RK45.__init__ (SCIPY/rk.py:84-104) ----
                     double c;
@@ -800,6 +815,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                     double d1 = rms3(fdiv(f0, s0), fdiv(f1, s1), fdiv(f2, s2));
                     double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : fdiv(0.01 * d0, d1);
                     if (!(h0 < interval)) h0 = interval;
+                    PGR_SSTAMP(14);   // restart: first right-hand side, d0, d1, h0
                     double e0, e1, e2, cdummy;
                     C.rhs(t + h0 * 1.0, y1 + h0 * 1.0 * f1, y2 + h0 * 1.0 * f2, e0, e1, e2, cdummy);
                     double d2 = fdiv(rms3(fdiv(e0 - f0, s0), fdiv(e1 - f1, s1), fdiv(e2 - f2, s2)), h0);
@@ -810,6 +826,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                     } else {
                         h1 = pgr_cr_pow_p02(fdiv(0.01, (d2 > d1) ? d2 : d1));
                     }
+                    PGR_SSTAMP(15);   // restart: second right-hand side, d2, the power
                     h_abs = 100 * h0;
                     if (h1 < h_abs) h_abs = h1;
                     if (interval < h_abs) h_abs = interval;
@@ -821,7 +838,9 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
                         jnext = G.nearest(t, as.inv_dsave);
                         rnext = G.at(jnext);
                     }
+                    PGR_SSTAMP(16);   // restart: events, nearest save point
                 }
+                PGR_SSTAMP(17);
             }
         }
     } while (ballot64(status == RUNNING) != 0);
@@ -839,10 +858,13 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
         const FanArgs __attribute__((address_space(4))) & a = *(KArgs)(kp + kFanArgsKernargOffset);  // (shadows the argument)
         if (BLK) {
             if (ok) {
-                // last column = exact final state (REF/launch_rays.py:775-777): into its slot, and the last block goes out
-                // (slots behind it hold an earlier block's samples: they land in the padding rows S ... 4 ceil(S/4) - 1)
-                double* const e = blk + ((S - 1) & 3) * 64;
+                // last column = exact final state (REF/launch_rays.py:775-777): into its slot, and the last block goes out;
+                // the slots behind it (an earlier block's samples) become NaN first, so that the padding rows S ... 4 ceil(S/4) - 1
+                // hold NaN for every ray -- a device-resident consumer may reduce over the whole padded buffer
+                const int last = (S - 1) & 3;
+                double* const e = blk + last * 64;
                 e[0] = y0; e[256] = SGN(y1); e[512] = SGN(y2);
+                for (int k = last + 1; k < 4; k++) { blk[k * 64] = nan; blk[256 + k * 64] = nan; blk[512 + k * 64] = nan; }
                 blk_flush((S - 1) >> 2);
             } else {
                 for (int k = 0; k < 12; k++) blk[k * 64] = nan;
@@ -880,7 +902,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
         a.n_surf[ray] = ns;
         a.status[ray] = status;
         if (a.n_steps) a.n_steps[ray] = n_steps;
-#ifdef PGR_TIMING
+#if defined(PGR_TIMING) || defined(PGR_SVC_TIMING)
         if ((threadIdx.x & 63) < 24) {
             unsigned v = 0;
             for (int k = 0; k < 24; k++) v = ((threadIdx.x & 63) == k) ? tacc[k] : v;

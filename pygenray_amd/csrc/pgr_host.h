@@ -39,6 +39,7 @@ struct pgr_env {
     int depth_search = 0;             // 0: automatic, 1: binary search only, 2: bucket table but no index polynomial (tests)
     int park_lanes = 64, park_trips = 10;
     int place = 2;                    // 0 off, 1 issue priorities only, 2 cost-aware placement + priorities
+    int api_blocked = 1;              // host-pointer entry / fan handles: HBM-table trajectory fans run the sample-blocked kernel (un-blocked on the way out)
     int persistent = 1;               // fans of several rounds: persistent waves claiming packets from the cost-sorted list (0: whole workgroups, static)
     hipStream_t stream = nullptr;     // the host-pointer entry's own stream (created on first use)
     EnvDev d{};

@@ -75,6 +75,48 @@ static int schedule_waves(pgr_env* env, const double* y0, int64_t N, int64_t wav
     return 0;
 }
 
+// Kernel variant of an environment: where the table lives (LDS copy of the single profile / HBM) and how a depth cell is
+// found (zm 1 / 4: zin[j] = j dz exactly, 5: cubic index estimate, 3: quadratic estimate + three nodes, 2: bin table -- zin
+// in LDS for those three --, 0: closed form for other uniform grids or binary search); zx_bytes = LDS the depth search takes.
+static void select_variant(const pgr_env* env, bool& lds_tab, int& zm, size_t& zx_bytes)
+{
+    const EnvDev& D = env->d;
+    const size_t tab_bytes = (size_t)D.nz * sizeof(double2);
+    const size_t zb_bytes = D.z_bucket ? ((size_t)D.nz * sizeof(double) + (((size_t)D.zb_B * 2 + 15) & ~(size_t)15)) : 0;
+    lds_tab = env->lds_path != 0;
+    zm = D.z_simple ? ((D.dz == 1.0) ? 4 : 1) : 0;
+    const size_t zq_bytes = (size_t)D.nz * sizeof(double);
+    zx_bytes = 0;
+    if (!D.z_simple && env->depth_search != 1) {
+        if (D.z_cubic && env->depth_search == 0) {
+            if (env->range_indep && tab_bytes + zq_bytes <= env->max_lds) { lds_tab = true; zm = 5; zx_bytes = zq_bytes; }
+            else if (zq_bytes <= env->max_lds) { lds_tab = false; zm = 5; zx_bytes = zq_bytes; }
+        }
+        if (zm == 0 && D.z_quad && (env->depth_search == 0 || env->depth_search == 3)) {
+            if (env->range_indep && tab_bytes + zq_bytes <= env->max_lds) { lds_tab = true; zm = 3; zx_bytes = zq_bytes; }
+            else if (zq_bytes <= env->max_lds) { lds_tab = false; zm = 3; zx_bytes = zq_bytes; }
+        }
+        if (zm == 0 && D.z_bucket) {
+            if (env->range_indep && tab_bytes + zb_bytes <= env->max_lds) { lds_tab = true; zm = 2; zx_bytes = zb_bytes; }
+            else if (zb_bytes <= env->max_lds) { lds_tab = false; zm = 2; zx_bytes = zb_bytes; }
+        }
+    }
+}
+
+// Would a trajectory fan of this environment run the sample-blocked kernel (PGR_SAMPLE_BLOCKED) if asked to?  The host-pointer
+// entry and the fan handles ask before they size their device buffers: tables in HBM / L2 (the LDS-table kernels gain
+// nothing from it), and room in the LDS for the staging of eight waves behind the depth search and the bathymetry.
+static bool blocked_layout_fits(const pgr_env* env)
+{
+    bool lds_tab;
+    int zm;
+    size_t zx_bytes;
+    select_variant(env, lds_tab, zm, zx_bytes);
+    if (lds_tab || !env->api_blocked) return false;
+    const size_t at = ((((zx_bytes + 15) & ~(size_t)15) + (size_t)env->d.nb * 16) + 15) & ~(size_t)15;
+    return at + 8 * 6144 <= env->max_lds;
+}
+
 extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, double source_range,
                                     double receiver_range, const double* r_save, int32_t S,
                                     double rtol, double atol, uint32_t flags, int64_t max_steps,
@@ -115,30 +157,13 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
 
     int64_t waves = (N + 63) / 64;
     hipStream_t st = (hipStream_t)stream;
-    // kernel variant: where the table lives (LDS copy of the single profile / HBM) and how a depth
-    // cell is found (1: zin[j] = j dz exactly, 2: bucket table + zin in LDS, 0: closed form for other
-    // uniform grids or binary search)
+    // kernel variant: where the table lives and how a depth cell is found (select_variant)
     const EnvDev& D = env->d;
     const size_t tab_bytes = (size_t)D.nz * sizeof(double2);
-    const size_t zb_bytes = D.z_bucket ? ((size_t)D.nz * sizeof(double) + (((size_t)D.zb_B * 2 + 15) & ~(size_t)15)) : 0;
-    bool lds_tab = env->lds_path != 0;
-    int zm = D.z_simple ? ((D.dz == 1.0) ? 4 : 1) : 0;
-    const size_t zq_bytes = (size_t)D.nz * sizeof(double);
-    size_t zx_bytes = 0;  // LDS taken by the depth search of the chosen variant
-    if (!D.z_simple && env->depth_search != 1) {
-        if (D.z_cubic && env->depth_search == 0) {
-            if (env->range_indep && tab_bytes + zq_bytes <= env->max_lds) { lds_tab = true; zm = 5; zx_bytes = zq_bytes; }
-            else if (zq_bytes <= env->max_lds) { lds_tab = false; zm = 5; zx_bytes = zq_bytes; }
-        }
-        if (zm == 0 && D.z_quad && (env->depth_search == 0 || env->depth_search == 3)) {
-            if (env->range_indep && tab_bytes + zq_bytes <= env->max_lds) { lds_tab = true; zm = 3; zx_bytes = zq_bytes; }
-            else if (zq_bytes <= env->max_lds) { lds_tab = false; zm = 3; zx_bytes = zq_bytes; }
-        }
-        if (zm == 0 && D.z_bucket) {
-            if (env->range_indep && tab_bytes + zb_bytes <= env->max_lds) { lds_tab = true; zm = 2; zx_bytes = zb_bytes; }
-            else if (zb_bytes <= env->max_lds) { lds_tab = false; zm = 2; zx_bytes = zb_bytes; }
-        }
-    }
+    bool lds_tab;
+    int zm;
+    size_t zx_bytes;  // LDS taken by the depth search of the chosen variant
+    select_variant(env, lds_tab, zm, zx_bytes);
     // PGR_SAMPLE_BLOCKED: everything that can be refused from the flags alone is refused HERE, before the scheduling below
     // claims a placement slot and queues its memset and two kernels on the caller's stream
     if (flags & PGR_SAMPLE_BLOCKED) {

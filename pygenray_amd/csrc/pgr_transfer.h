@@ -15,6 +15,28 @@ __global__ void pgr_gather_cols(const double* __restrict__ src, double* __restri
     dst[s * M + m] = src[s * N + idx[m]];
 }
 
+// The same squeeze out of a sample-BLOCKED array [ceil(S/4)][N][4] (PGR_SAMPLE_BLOCKED): dst[4 b + q][m] = src[b][idx[m]][q].
+// One thread per (block b, surviving ray m): it reads the ray's four samples as one 32-byte piece (adjacent rays: adjacent
+// pieces) and writes them into four rows (a wave: four 512-byte runs).  idx == nullptr: every ray is kept (m = k).  This
+// is how the host-pointer entry and the fan handles hand API callers of HBM-table environments plain [S][M] arrays while
+// the fan kernel writes full 32-byte pieces (REF/launch_rays.py:166-186 is what the caller gets either way).
+__global__ void pgr_unblock_cols(const double* __restrict__ src, double* __restrict__ dst,
+                                 const int* __restrict__ idx, int64_t M, int64_t N, int S)
+{
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const int64_t b = blockIdx.y;
+    const int64_t k = idx ? (int64_t)idx[m] : m;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2* p = (const d2*)(src + (b * N + k) * 4);
+    const d2 lo = __builtin_nontemporal_load(p), hi = __builtin_nontemporal_load(p + 1);
+    const int64_t j = 4 * b;
+    dst[j * M + m] = lo.x;
+    if (j + 1 < S) dst[(j + 1) * M + m] = lo.y;
+    if (j + 2 < S) dst[(j + 2) * M + m] = hi.x;
+    if (j + 3 < S) dst[(j + 3) * M + m] = hi.y;
+}
+
 // Device -> host copy of a list of (large) arrays into the caller's pageable buffers, pipelined with the page
 // faults those buffers still owe.  Measured on the one-GPU box (scripts/probes/pcie_probe2.py, 0.8 GB pieces): a D2H
 // copy into never-touched NumPy memory runs at the page-fault rate of one thread (15-17 GB/s), into touched memory
@@ -223,8 +245,25 @@ extern "C" int pgr_shoot_fan(pgr_env* env, const double* y0, int64_t N, double s
     HIPCHK(hipSetDevice(env->device));
     std::lock_guard<std::mutex> lock(env->ws_mutex);
     size_t ns_bytes = (size_t)N * (size_t)(save ? S : 0) * sizeof(double);
+    // is r_save exactly np.linspace(source_range, receiver_range, S)?  then the kernel recomputes it per index instead
+    // of loading it
+    bool lin = save;
+    if (save) {
+        const double step = (S > 1) ? (receiver_range - source_range) / (double)(S - 1) : 0.0;
+        for (int32_t j = 0; j < S && lin; j++) {
+            volatile double m = (double)j * step;
+            volatile double v = m + source_range;
+            double want = (j == S - 1 && S > 1) ? receiver_range : (double)v;
+            lin = (r_save[j] == want);
+        }
+        if (lin) flags |= PGR_SAVE_LINSPACE; else flags &= ~PGR_SAVE_LINSPACE;
+    }
+    // Environments whose tables stay in HBM / L2: the trajectories are integrated by the sample-blocked kernel (device
+    // buffers [ceil(S/4)][N][4]) and un-blocked to the caller's [S][N] / [S][M] by the pass that squeezes dropped rays out
+    const bool blocked = save && lin && (flags & PGR_SAMPLE_MAJOR) && !(flags & PGR_EXACT_SAMPLES) && blocked_layout_fits(env);
+    const size_t dev_ns_bytes = blocked ? (size_t)N * (size_t)(4 * ((S + 3) / 4)) * sizeof(double) : ns_bytes;
     // carve one workspace: y0, r_save, T, Z, P, end, 5 int arrays (256-byte aligned pieces)
-    const size_t sizes[11] = {(size_t)N * 24, (size_t)(save ? S : 1) * 8, ns_bytes, ns_bytes, ns_bytes,
+    const size_t sizes[11] = {(size_t)N * 24, (size_t)(save ? S : 1) * 8, dev_ns_bytes, dev_ns_bytes, dev_ns_bytes,
                               (size_t)N * 24, (size_t)N * 4, (size_t)N * 4, (size_t)N * 4, (size_t)N * 4,
                               (size_t)N * 4};
     size_t off[11], total = 0;
@@ -254,21 +293,8 @@ extern "C" int pgr_shoot_fan(pgr_env* env, const double* y0, int64_t N, double s
     hipStream_t st = env->stream;
     HIPCHK(hipMemcpyAsync(dy0.p, y0, N * 3 * sizeof(double), hipMemcpyHostToDevice, st));
     if (save) HIPCHK(hipMemcpyAsync(dr.p, r_save, (size_t)S * sizeof(double), hipMemcpyHostToDevice, st));
-    if (save) {
-        // is r_save exactly np.linspace(source_range, receiver_range, S)?  then the kernel
-        // recomputes it per index instead of loading it
-        double step = (S > 1) ? (receiver_range - source_range) / (double)(S - 1) : 0.0;
-        bool lin = true;
-        for (int32_t j = 0; j < S && lin; j++) {
-            volatile double m = (double)j * step;
-            volatile double v = m + source_range;
-            double want = (j == S - 1 && S > 1) ? receiver_range : (double)v;
-            lin = (r_save[j] == want);
-        }
-        if (lin) flags |= PGR_SAVE_LINSPACE; else flags &= ~PGR_SAVE_LINSPACE;
-    }
     int rc = pgr_shoot_fan_device(env, (const double*)dy0.p, N, source_range, receiver_range,
-                                  (const double*)dr.p, S, rtol, atol, flags, max_steps,
+                                  (const double*)dr.p, S, rtol, atol, flags | (blocked ? PGR_SAMPLE_BLOCKED : 0u), max_steps,
                                   save ? (double*)dT.p : nullptr, save ? (double*)dZ.p : nullptr,
                                   save ? (double*)dP.p : nullptr, (double*)dE.p, (int32_t*)dnb.p,
                                   (int32_t*)dns.p, (int32_t*)dst.p, (int32_t*)dn1.p, (int32_t*)dn2.p,
@@ -284,13 +310,17 @@ extern "C" int pgr_shoot_fan(pgr_env* env, const double* y0, int64_t N, double s
     auto ready = [&](std::vector<D2HJob>& jb) -> int {
         HIPCHK(hipMemcpyAsync(status, dst.p, N * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));       // the kernel has finished
-        if (!(save && (flags & PGR_COMPACT))) return 0;
-        if (!(flags & PGR_SAMPLE_MAJOR)) return fail("pgr_shoot_fan: PGR_COMPACT needs PGR_SAMPLE_MAJOR");
+        const bool compact = save && (flags & PGR_COMPACT);
+        if (!compact && !blocked) return 0;
+        if (compact && !(flags & PGR_SAMPLE_MAJOR)) return fail("pgr_shoot_fan: PGR_COMPACT needs PGR_SAMPLE_MAJOR");
         if (N > 0x7fffffff) return fail("pgr_shoot_fan: PGR_COMPACT supports at most 2^31 rays per call");
-        keep.reserve((size_t)N);
-        for (int64_t k = 0; k < N; k++) if (status[k] == 0) keep.push_back((int)k);
-        const int64_t M = (int64_t)keep.size();
-        if (M == N) return 0;
+        int64_t M = N;
+        if (compact) {
+            keep.reserve((size_t)N);
+            for (int64_t k = 0; k < N; k++) if (status[k] == 0) keep.push_back((int)k);
+            M = (int64_t)keep.size();
+        }
+        if (M == N && !blocked) return 0;
         const size_t mbytes = (size_t)S * (size_t)M * sizeof(double), piece = (mbytes + 255) & ~(size_t)255;
         const size_t need2 = 3 * piece + (((size_t)M * 4 + 255) & ~(size_t)255) + 256;
         if (need2 > env->ws2_bytes) {
@@ -301,11 +331,16 @@ extern "C" int pgr_shoot_fan(pgr_env* env, const double* y0, int64_t N, double s
         }
         int* didx = (int*)((char*)env->ws2 + 3 * piece);
         if (M > 0) {
-            HIPCHK(hipMemcpyAsync(didx, keep.data(), (size_t)M * sizeof(int), hipMemcpyHostToDevice, st));
+            const bool all = (M == N);     // (blocked and nothing dropped, or no compaction asked for: un-block every ray)
+            if (!all) HIPCHK(hipMemcpyAsync(didx, keep.data(), (size_t)M * sizeof(int), hipMemcpyHostToDevice, st));
             for (int a3 = 0; a3 < 3; a3++) {
                 double* tmp = (double*)((char*)env->ws2 + (size_t)a3 * piece);
-                hipLaunchKernelGGL(pgr_gather_cols, dim3((unsigned)((M + 255) / 256), (unsigned)S), dim3(256), 0, st,
-                                   (const double*)jb[a3].src, tmp, (const int*)didx, M, N);
+                if (blocked)
+                    hipLaunchKernelGGL(pgr_unblock_cols, dim3((unsigned)((M + 255) / 256), (unsigned)((S + 3) / 4)), dim3(256), 0, st,
+                                       (const double*)jb[a3].src, tmp, all ? (const int*)nullptr : (const int*)didx, M, N, (int)S);
+                else
+                    hipLaunchKernelGGL(pgr_gather_cols, dim3((unsigned)((M + 255) / 256), (unsigned)S), dim3(256), 0, st,
+                                       (const double*)jb[a3].src, tmp, (const int*)didx, M, N);
                 HIPCHK(hipGetLastError());
                 jb[a3].src = tmp;
             }

@@ -44,12 +44,30 @@ def ray_angle(x, y, cin, rin, zin):
 _EVAL_ENVS = {}   # (ids + shapes of the tables) -> (EnvHandle, the arrays themselves, their content fingerprint); FIFO
 
 
+_FULL_HASH_BYTES = 1 << 20     # arrays up to 1 MB are hashed whole (~0.5 ms); larger ones by a strided sample
+
+
 def _fingerprint(arrs):
-    """Content of the tables (crc32 of each array's bytes): the reference's functions are pure functions of their array
-    arguments, so a caller that edits a table in place (cin += dc in a sensitivity loop) must not be served from the
-    tables uploaded before the edit."""
+    """Content of the tables: the reference's functions are pure functions of their array arguments, so a caller that
+    edits a table in place (cin += dc in a sensitivity loop) must not be served from the tables uploaded before the
+    edit.  The reference calls its event functions point by point, so this runs per scalar query and has to be cheap:
+    arrays up to 1 MB are hashed whole (crc32); of a larger one (tens of MB of cin / cpin) shape, dtype and a strided
+    sample of 65 536 elements that always includes the first and the last -- every edit of a whole table or of a whole
+    row / column is seen, an edit of single elements of a large table may not be: call ``clear_eval_cache()`` after
+    such an edit.  No copy is made of an array that is float64 and C-contiguous already."""
     import zlib
-    return tuple(zlib.crc32(np.ascontiguousarray(a, dtype=np.float64)) for a in arrs)
+    out = []
+    for a in arrs:
+        a = np.asarray(a)
+        if a.nbytes <= _FULL_HASH_BYTES:
+            b = a if (a.dtype == np.float64 and a.flags.c_contiguous) else np.ascontiguousarray(a, dtype=np.float64)
+            out.append((a.shape, zlib.crc32(b)))
+        else:
+            flat = a.reshape(-1) if a.flags.c_contiguous else a.ravel()
+            step = max(1, flat.size // 65536) | 1          # odd: walks through every column of a 2-D table
+            out.append((a.shape, str(a.dtype), zlib.crc32(np.ascontiguousarray(flat[::step])),
+                        float(flat[0]), float(flat[-1])))
+    return tuple(out)
 
 
 def _device_eval(x, y, cin, cpin, rin, zin, depths, depth_ranges):

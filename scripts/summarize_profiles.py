@@ -64,6 +64,58 @@ if fe is not None and wr is not None:
 st = glob.glob(os.path.join(G, f"{tag}_rangedep_blocked_stats", "*", "*_kernel_stats.csv"))
 if st:
     shutil.copy(st[0], os.path.join(ROOT, "profiles", f"{rnd}_kernel_stats_rangedep_blocked.csv"))
+# ---- round 5: the 1e6-ray leg (persistent waves), the lone steepest wave, pr.shoot_rays on configs[2]
+def all_counters(d, needle, n_last=1):
+    """the counter of directory d summed over the LAST n_last dispatches of the kernels whose name holds `needle`"""
+    f = glob.glob(os.path.join(G, d, "*", "*_counter_collection.csv"))
+    if not f:
+        return None
+    per = {}
+    for r in csv.DictReader(open(f[0])):
+        if needle in r["Kernel_Name"]:
+            per.setdefault(r["Dispatch_Id"], 0.0)
+            per[r["Dispatch_Id"]] += float(r["Counter_Value"])
+    return sum(per[k] for k in sorted(per, key=int)[-n_last:]) if per else None
+
+
+fe, wr = fan_counters(f"{tag}_1e6_FETCH_SIZE").get("FETCH_SIZE"), fan_counters(f"{tag}_1e6_WRITE_SIZE").get("WRITE_SIZE")
+if fe is not None and wr is not None:
+    out["sample-nosave@1000000"] = {"rays": 1000000, "FETCH_SIZE_KB": fe, "WRITE_SIZE_KB": wr, "hbm_gb_per_launch": (2 * fe + wr) * 1024 / 1e9,
+                                    "note": f"profiles/{rnd}_traffic.json: rocprofv3 PMC passes (FETCH_SIZE x 2 per the gfx950 correction + WRITE_SIZE), "
+                                            "fan kernel pgr_fan_kernel<true, 4, 0, true> (persistent waves), last dispatch",
+                                    "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --rays 1000000 "
+                                               "--no-save --steps 2 --warmup 1 --no-cpu-baseline --no-eigenray --no-legs"}
+    sq = fan_counters(f"{tag}_1e6_sq")
+    if sq:
+        out["sample-nosave@1000000-sq_counters"] = sq
+        out["sample-nosave@1000000"]["valu_wave_instructions_per_launch"] = sq.get("SQ_INSTS_VALU")
+for what, name in (("1e6", "1e6"), ("lone", "lone_wave"), ("api2", "api_config2")):
+    st = glob.glob(os.path.join(G, f"{tag}_{what}_stats", "*", "*_kernel_stats.csv"))
+    if st:
+        shutil.copy(st[0], os.path.join(ROOT, "profiles", f"{rnd}_kernel_stats_{name}.csv"))
+api = {}
+for mode in ("blocked", "rows"):
+    row = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        for kern, needle in (("fan_kernel", "pgr_fan_kernel"), ("unblock_or_gather", "cols")):
+            v = all_counters(f"{tag}_api2_{mode}_{c}", needle, 1 if kern == "fan_kernel" else 3)   # (T, z, p: three passes)
+            if v is not None:
+                row[f"{kern}_{c}_KB"] = v
+        lg = os.path.join(G, f"{tag}_api2_{mode}_{c}.log")
+        if os.path.exists(lg):
+            for ln in open(lg):
+                if ln.startswith("{"):
+                    row.update({k: v for k, v in json.loads(ln).items() if k in ("rays_kept", "sample_bytes")})
+    if row:
+        if "fan_kernel_WRITE_SIZE_KB" in row and "sample_bytes" in row:
+            # (the fan kernel writes the samples of ALL 1e5 rays, dropped ones as NaN columns; the host gets the survivors')
+            row["fan_kernel_write_over_sample_bytes"] = row["fan_kernel_WRITE_SIZE_KB"] * 1024 / (100000 * 1001 * 24)
+        api[mode] = row
+if api:
+    api["command"] = "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 scripts/api_cfg2_run.py blocked|rows"
+    api["note"] = ("pr.shoot_rays on configs[2] (1e5 rays, S = 1001, eager): the LAST dispatch of the fan kernel and of the pass that squeezes dropped "
+                   "rays out (pgr_unblock_cols / pgr_gather_cols), each array's pass summed; blocked = PGR_OPT_API_BLOCKED 1 (default)")
+    out["api-config2"] = api
 b = os.path.join(G, f"{tag}_binary.json")
 if os.path.exists(b):
     out.update(json.load(open(b)))

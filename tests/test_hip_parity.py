@@ -1397,6 +1397,110 @@ def test_wave_scheduler_is_a_pure_permutation(lib):
         env2.set_option("park", 0, 5)
 
 
+def test_persistent_waves_hold_the_same_bits_as_the_static_deal(lib):
+    """Fans of several rounds (more 64-ray packets than the chip holds waves) run as PERSISTENT waves that claim packets
+    from the cost-sorted list (PGR_OPT_PERSISTENT 1, the default); the static deal of whole workgroups (0) and the
+    plain strided deal (placement 0) integrate the same rays: every output array bit-identical, every ray integrated
+    exactly once -- LDS-table and HBM-table kernels, end state only, rows, the sample-blocked layout, the cubic-index
+    look-up -- and every 400th ray of the largest fan bit-identical to the oracle."""
+    from pygenray_amd.device_fan import DeviceFan
+    import torch
+    cus = 256
+
+    def run(env, y0, x1, S, save, blocked=False):
+        fan = DeviceFan(env, y0, 0.0, x1, S, save=save, sample_major=True, sample_blocked=blocked)
+        fan.run(); torch.cuda.synchronize()
+        out = {k: getattr(fan, k).cpu().numpy() for k in ("end", "n_bott", "n_surf", "status", "n_steps", "n_rej")}
+        if save:
+            out.update({k: fan.rows(getattr(fan, k)).cpu().numpy() for k in ("T", "Z", "P")})
+        return out
+
+    arrs = munk_arrays(80e3, nr=12)
+    arrs_rd = munk_arrays(80e3, nr=13, sofar_slope=1e-3)
+    import pygenray_amd as pr
+    from pygenray_amd.environment import _unpack_envi
+    z = np.arange(0, 6000, 1.0); r = np.linspace(0, 80e3, 9)
+    eo = pr.OceanEnvironment2D(pr.DataArray(np.tile(pr.munk_ssp(z), (9, 1)), dims=["range", "depth"], coords={"range": r, "depth": z}),
+                               pr.DataArray(np.full(9, 5000.0), dims=["range"], coords={"range": r}), flat_earth_transform=True)
+    arrs_fe = _unpack_envi(eo, flatearth=True)
+    cases = [(arrs, 8 * cus * 64 + 65, 1, False, False), (arrs, 200_001, 7, True, False), (arrs_rd, 160_000, 1, False, False),
+             (arrs_rd, 140_000, 10, True, True), (arrs_rd, 140_000, 9, True, False), (arrs_fe, 150_000, 5, True, False)]
+    for arrs_, n, S, save, blocked in cases:
+        env = lib.EnvHandle(*arrs_)
+        y0 = y0_for(oracle, arrs_, 900.0, 0.0, np.linspace(-19.5, 19.5, n))
+        env.set_option("persistent", 0)
+        ref = run(env, y0, 80e3, S, save, blocked)
+        env.set_option("persistent", 1)
+        got = run(env, y0, 80e3, S, save, blocked)
+        for k in ref:
+            assert np.array_equal(got[k], ref[k], equal_nan=True), (n, S, blocked, k)
+        env.set_option("placement", 0)
+        plain = run(env, y0, 80e3, S, save, blocked)
+        for k in ref:
+            assert np.array_equal(plain[k], ref[k], equal_nan=True), (n, S, blocked, k, "strided")
+        if arrs_ is arrs and save:
+            sub = np.arange(0, n, 400)
+            o = oracle.shoot_fan(*arrs_, y0[sub], 0.0, 80e3, S, math=oracle.MATH_CR)
+            assert np.array_equal(o["status"], got["status"][sub]) and np.array_equal(o["n_steps"], got["n_steps"][sub])
+            ok = o["status"] == 0
+            end_o = np.stack([o["T"][:, -1], o["z"][:, -1], o["p"][:, -1]], 1)
+            assert np.array_equal(end_o[ok], got["end"][sub][ok]) and np.array_equal(o["n_rej"][ok], got["n_rej"][sub][ok])
+        env.close()
+
+
+def test_api_callers_of_hbm_table_environments_get_the_sample_blocked_kernel(lib):
+    """pgr_shoot_fan (sample-major) and the fan handles integrate trajectory fans of environments whose tables stay in HBM / L2
+    with the sample-blocked kernel and un-block in the pass that squeezes dropped rays out (PGR_OPT_API_BLOCKED 1, the
+    default): the caller's arrays are the row kernel's, bit for bit -- with and without compaction, for every S mod 4,
+    with dropped rays, eager and device resident, through pr.shoot_rays too (REF/launch_rays.py:166-186 is what the caller
+    gets either way)."""
+    import pygenray_amd as pr
+    arrs = munk_arrays(100e3, nr=21, z=np.arange(0, 4000, 1.0), bathy=5000.0, sofar_slope=5e-4)   # range dependent; deep rays leave the table
+    theta = np.linspace(-20, 20, 700)
+    y0 = y0_for(oracle, arrs, 1000.0, 0.0, -theta)
+    env = lib.EnvHandle(*arrs)
+    assert not env.lds_path
+    for S in (1, 2, 3, 4, 41, 42, 43, 44):
+        for compact in (False, True):
+            env.set_option("api_blocked", 0)
+            ref = env.shoot_fan(y0, 0.0, 100e3, S, sample_major=True, stored_sign=True, compact=compact)
+            env.set_option("api_blocked", 1)
+            got = env.shoot_fan(y0, 0.0, 100e3, S, sample_major=True, stored_sign=True, compact=compact)
+            assert 10 < (ref["status"] != 0).sum() < 600
+            for k in ("T", "z", "p", "end", "status", "n_bott", "n_surf", "n_steps", "n_rej"):
+                assert got[k].shape == ref[k].shape and np.array_equal(got[k], ref[k], equal_nan=True), (S, compact, k)
+    # the oracle on the blocked path's output (rule A: bit for bit, every sample in SciPy's order is not what the default
+    # form gives inside a step -- end states and counts are)
+    o = oracle.shoot_fan(*arrs, y0[::7], 0.0, 100e3, 44, math=oracle.MATH_CR)
+    assert np.array_equal(o["status"], got["status"][::7]) and np.array_equal(o["n_steps"], got["n_steps"][::7])
+    ok = o["status"] == 0
+    assert np.array_equal(np.stack([o["T"][:, -1], o["z"][:, -1], o["p"][:, -1]], 1)[ok], got["end"][::7][ok])
+    # fan handles: compact and full fetches, one array at a time
+    drop = ref["status"] != 0
+    for S in (41, 43):
+        env.set_option("api_blocked", 0)
+        ref = env.shoot_fan(y0, 0.0, 100e3, S, sample_major=True, stored_sign=True)
+        env.set_option("api_blocked", 1)
+        h = lib.FanHandle(env, 0.0, 100e3, S, y0=y0, stored_sign=True)
+        full = h.fetch_samples(compact=False)
+        for k in "Tzp":
+            assert full[k].shape == (S, 700) and np.array_equal(full[k], ref[k], equal_nan=True), (S, k)
+        only_p = h.fetch_samples(("p",))
+        assert list(only_p) == ["p"] and np.array_equal(only_p["p"], ref["p"][:, ~drop])
+        h.close()
+    env.close()
+    # the drop-in API on a range-dependent environment, eager and device resident
+    z = np.arange(0, 4000, 1.0); r = np.linspace(0, 100e3, 21)
+    c2 = np.array([pr.munk_ssp(z, 1300.0 + 5e-4 * ri) for ri in r])
+    eo = pr.OceanEnvironment2D(pr.DataArray(c2, dims=["range", "depth"], coords={"range": r, "depth": z}),
+                               pr.DataArray(np.full(21, 5000.0), dims=["range"], coords={"range": r}), flat_earth_transform=False)
+    a = pr.shoot_rays(1000.0, 0.0, theta, 100e3, 41, eo, debug=False, flatearth=False, device_resident=False)
+    b = pr.shoot_rays(1000.0, 0.0, theta, 100e3, 41, eo, debug=False, flatearth=False, device_resident=True)
+    assert len(a) == len(b) == int((~drop).sum())
+    for k in ("thetas", "n_botts", "n_surfs", "rs", "zs", "ts", "ps"):
+        assert np.array_equal(getattr(a, k), getattr(b, k)), k
+
+
 def test_plain_c_example_runs(lib, tmp_path):
     """examples/shoot_fan.c (C99, no Python, no torch) drives the library and gets the oracle's rays."""
     import re
@@ -1520,6 +1624,14 @@ def test_receiver_depths_searched_together_equal_one_search_each(lib):
         assert np.all(np.abs(all4.zs[k][:, -1] + rd) < 1.0)
     # (each search: its loop + one re-shoot of the eigenrays found; together: the longest loop + one re-shoot)
     assert launches_together == max(launches_alone) and sum(launches_alone) > 2 * launches_together
+    # ONE arithmetic for the initial slowness (NumPy's sin(radians(.)) / c, REF/launch_rays.py:284-285) in the fan, in the
+    # search's trial rays and in the eigenrays handed back: pr.shoot_ray(theta) of an eigenray's launch angle IS that eigenray
+    for k in (0, 2):
+        for q in range(min(3, len(all4.launch_angles[k]))):
+            ray = pr.shoot_ray(1000.0, 0.0, float(all4.launch_angles[k][q]), 300e3, 51, env, debug=False, flatearth=False)
+            assert ray is not None and np.array_equal(ray.z, all4.zs[k][q]) and np.array_equal(ray.t, all4.ts[k][q]) \
+                and np.array_equal(ray.p, all4.ps[k][q]), (k, q)
+            assert ray.launch_angle == -all4.launch_angles[k][q]       # (Q2: shoot_ray stores the negated angle)
 
 
 def test_config4_end_records_and_arrival_time_histogram_of_1e6_rays(lib):
