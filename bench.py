@@ -255,9 +255,11 @@ def extra_legs():
         "trajectories_row_layout": kernel_leg(arrs_rd, RAYS_PER_GPU, True)}
     _, arrs1 = munk_tables(RANGE_M)
     legs["rays_1e6"] = {
-        "workload": "configs[1] tables, 1e6 launch angles (the per-GPU fan of configs[3] / configs[4]), end state only",
+        "workload": "configs[1] tables, 1e6 launch angles (the per-GPU fan of configs[3] / configs[4]): end state only, and with S = 1001 trajectories",
         "kernel": "pgr_fan_kernel<true, 4, 0, true> (persistent waves: one workgroup per CU, 64-ray packets claimed from the cost-sorted list)",
-        "end_state": kernel_leg(arrs1, 1_000_000, False, passes=3)}
+        "end_state": kernel_leg(arrs1, 1_000_000, False, passes=3),
+        # the headline's own kernel shape (S = 1001 trajectories, 24 GB of samples in HBM) at ten times its rays
+        "trajectories": kernel_leg(arrs1, 1_000_000, True, passes=3)}
     lone = {"end_state": kernel_leg(arrs1, RAYS_PER_GPU, False, rays_lo=(0, 64)),
             "trajectories": kernel_leg(arrs1, RAYS_PER_GPU, True, rays_lo=(0, 64))}
     return legs, lone
@@ -363,6 +365,22 @@ def api_leg(env_obj, calls=3, what="configs[1]"):
                      "bytes_to_host_inside_the_call": int(nbytes if not mode else kept * (3 * 8 + 8 + 4 + 4)),
                      "pcie_floor_ms_at_56GBs": 1e3 * nbytes / 56e9}
     return out
+
+
+def fma_leg():
+    """OPTIONAL, separately labelled, never the headline: the same sources built with FMA contraction allowed
+    (pygenray_amd/csrc/libpgr_hip_fma.so, built by __graft_entry__.build beside the product) on the headline fan, in a
+    child process (one library per process), with its deviation from the reference's vectors g11-g13 against the
+    reference's own self-noise -- what the bit-identical default costs and what it buys (scripts/fma_leg.py)."""
+    lib = os.path.join(ROOT, "pygenray_amd", "csrc", "libpgr_hip_fma.so")
+    if not os.path.exists(lib):
+        return None
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fma_leg.py"), "--lib", lib], capture_output=True, text=True, timeout=300)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        return json.loads(line[-1]) if (r.returncode == 0 and line) else {"error": (r.stderr or r.stdout)[-400:]}
+    except Exception as exc:   # noqa: BLE001  (an optional leg must not cost the line)
+        return {"error": f"{type(exc).__name__}: {exc}"}
 
 
 def eigenray_leg(env_obj, n_rays):
@@ -681,11 +699,15 @@ def main(argv=None):
             # <false, 4, 3> and is un-blocked by the pass that squeezes its dropped rays out (PGR_OPT_API_BLOCKED)
             env_rd, _ = munk_tables(RANGE_M, nr=101, sofar_slope=2e-4)
             legs["api_config2"] = api_leg(env_rd, what="configs[2] (range-dependent tables: sample-blocked kernel, un-blocked on the way out)")
+            fl = fma_leg()
+            if fl is not None:
+                legs["fma_contracted"] = fl
             out["legs"] = legs
             # the fan cannot finish before its steepest rays do: the first wave of the fan (64 steepest rays) ALONE
             out["lone_wave_ms"] = {"end_state": lone["end_state"]["kernel_ms"], "trajectories": lone["trajectories"]["kernel_ms"],
                                    "note": "rays 0..63 of the 1e5-ray fan alone on the chip: the floor of the fan's kernel time"}
             out["roofline"]["frac_rays_1e6_end_state"] = legs["rays_1e6"]["end_state"]["frac"]
+            out["roofline"]["frac_rays_1e6_trajectories"] = legs["rays_1e6"]["trajectories"]["frac"]
         emit(out)
     if use_dist:
         dist.barrier()

@@ -60,8 +60,15 @@ for rep in range(a.reps):
     wg_last = np.maximum.reduceat(e[order], idx)
     wg_waves = np.diff(np.append(idx, len(order)))
     wpb = int(wg_waves.max())
-    held = ((wg_last - wg_first) * wpb).sum()                     # slot-ms held by workgroups (empty slots of short workgroups included)
     running = dur.sum()
+    if a.persistent and wpb > 8:
+        # persistent waves: a workgroup IS its CU for the whole launch and `wg_waves` counts the packets it claimed; the
+        # slots are its 8 resident waves, and nothing is "held by a workgroup that waits for its last wave"
+        packets_per_cu, wpb = wpb, 8
+        held = running
+    else:
+        packets_per_cu = None
+        held = ((wg_last - wg_first) * wpb).sum()                 # slot-ms held by workgroups (empty slots of short workgroups included)
     tail_in_wg = held - running
     slots = n_cu * wpb                                           # wave slots the launch can fill at once (one workgroup per CU)
     total = slots * span
@@ -82,7 +89,7 @@ for rep in range(a.reps):
     # the launch's tail: from the moment the first SIMD runs dry for good (its last wave ended) to the end
     last_end = np.array([e[simd == sid].max() for sid in np.unique(simd)])
     out = {"rays": n, "save": bool(a.save), "persistent": a.persistent, "rep": rep, "kernel_ms_hip_events": ms, "span_ms_stamps": float(span),
-           "waves": int(nw), "workgroups": int(len(wg_s)), "waves_per_workgroup": wpb, "cus_seen": int(n_cu), "simds_seen": int(n_simd),
+           "waves": int(nw), "workgroups": int(len(wg_s)), "waves_per_workgroup": wpb, "max_packets_claimed_by_one_cu": packets_per_cu, "cus_seen": int(n_cu), "simds_seen": int(n_simd),
            "wave_ms": {"min": float(dur.min()), "median": float(np.median(dur)), "max": float(dur.max()), "sum_slot_ms": float(running)},
            "slot_time_split": {"total_slot_ms": float(total), "running_waves": float(running / total),
                                "idle_inside_a_resident_workgroup": float(tail_in_wg / total),

@@ -593,6 +593,33 @@ def test_round4_profiles_and_bench_line():
     assert reh["legs"]["config4"]["histogram_counted_rays"] == reh["legs"]["config4"]["gathered_ok"]
 
 
+def test_eval_cache_fingerprint_is_cheap_and_sees_in_place_edits():
+    """host_physics._fingerprint (the content check of the tables kept on the device for point-by-point derivsrd / event
+    calls): whole-array hashes up to 1 MB, a strided sample beyond -- an in-place edit of a whole table, of a row, of a
+    column or of its ends changes it; a large table costs well under a millisecond per query."""
+    import time
+    from pygenray_amd.host_physics import _fingerprint
+    rng = np.random.default_rng(3)
+    small = [rng.normal(size=(20, 300)), rng.normal(size=(20, 300)), np.arange(20.0), np.arange(300.0), np.ones(20), np.arange(20.0)]
+    f0 = _fingerprint(small)
+    small[0][7, 123] += 1e-9
+    f1 = _fingerprint(small)
+    assert f0 != f1 and _fingerprint(small) == f1            # a single element of a small table
+    big = [rng.normal(size=(400, 6000)), rng.normal(size=(400, 6000)), np.arange(400.0), np.arange(6000.0), np.ones(400), np.arange(400.0)]
+    f0 = _fingerprint(big)
+    for edit in (lambda a: a.__iadd__(1e-9), lambda a: a[17].__iadd__(1e-9), lambda a: a[:, 4321].__iadd__(1e-9),
+                 lambda a: a[-1:, -1:].__iadd__(1e-9), lambda a: a[:1, :1].__iadd__(1e-9)):
+        edit(big[0])
+        f1 = _fingerprint(big)
+        assert f1 != f0
+        f0 = f1
+    t0 = time.perf_counter()
+    for _ in range(20):
+        _fingerprint(big)
+    assert (time.perf_counter() - t0) / 20 < 5e-3           # (19 MB tables: was ~40 ms per query with whole-array crc32)
+    assert _fingerprint([np.arange(5, dtype=np.int32)]) == _fingerprint([np.arange(5.0)])     # content, not dtype, for small arrays
+
+
 def test_device_code_hash_reads_the_built_library():
     """_lib.device_code_sha256: the gfx950 .text inside the library's fat binary (no GPU needed)."""
     from pygenray_amd import _lib
@@ -669,6 +696,13 @@ def test_bench_gpus_n_starts_n_ranks_itself():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launcher-only", "--backend", "gloo"],
                        env=env2, capture_output=True, text=True, timeout=120)
     assert r.returncode == 2 and "WORLD_SIZE 3" in r.stderr
+    # the driver's 8-GPU shape: eight ranks start, join and report (the one-GPU box may hold at most six processes on its
+    # card, so the eight-rank rehearsal of the launcher is this CPU one; six ranks share the GPU in profiles/r05_*6ranks*)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--launcher-only", "--backend", "gloo"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1 and json.loads(line[0]) == {"launcher_only": True, "n_gpus": 8, "ranks_joined": 8}
 
 
 def test_real_xarray_and_xr_lite_unpack_to_the_same_arrays():
