@@ -593,6 +593,74 @@ def test_round4_profiles_and_bench_line():
     assert reh["legs"]["config4"]["histogram_counted_rays"] == reh["legs"]["config4"]["gathered_ok"]
 
 
+def test_round5_profiles_and_bench_line():
+    """profiles/r05_*: ONE binary -- every file that names a device_code_sha256 names the one the committed bench line was
+    produced with --, kernel stats for the persistent 1e6-ray instance and the lone steepest wave, the API's blocked-kernel
+    write traffic, the all-rays parity logs, the bench line's new legs and the five-rank rehearsal's per-GPU roofline."""
+    import glob
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    P = os.path.join(root, "profiles")
+    tr = json.load(open(os.path.join(P, "r05_traffic.json")))
+    sha = tr["device_code_sha256"]
+    assert len(sha) == 64 and tr["build"].startswith("layout: relaid")
+    named = 0
+    for f in sorted(glob.glob(os.path.join(P, "r05_*"))):
+        txt = open(f).read()
+        if f.endswith(".json"):
+            d = json.loads(txt)
+            d = d[0] if isinstance(d, list) else d
+            for key in ("device_code_sha256", "device_code_sha256_of_the_product_it_was_built_beside"):
+                if key in d:
+                    assert d[key] == sha, (os.path.basename(f), key)
+                    named += 1
+        else:
+            for m in re.finditer(r"device_code_sha256 ([0-9a-f]{64})", txt):
+                assert m.group(1) == sha, os.path.basename(f)
+                named += 1
+    assert named >= 12
+    for v, tags in (("", ["<true, 4, 1, false>"]), ("_flatearth", ["<true, 5, 1, false>"]), ("_rangedep", ["<false, 4, 1, false>"]),
+                    ("_rangedep_blocked", ["<false, 4, 3, false>"]), ("_1e6", ["<true, 4, 0, true>"]),
+                    ("_lone_wave", ["<true, 4, 1, false>", "<true, 4, 0, false>"]), ("_api_config2", ["<false, 4, 3, false>", "pgr_unblock_cols"])):
+        txt = open(os.path.join(P, f"r05_kernel_stats{v}.csv")).read()
+        for t in tags:
+            assert ("pgr_fan_kernel" + t if t.startswith("<") else t) in txt, (v, t)
+    # the 1e6-ray leg: rocprofv3's average of the persistent instance agrees with the bench line's HIP events
+    row = [ln for ln in open(os.path.join(P, "r05_kernel_stats_1e6.csv")) if "<true, 4, 0, true>" in ln][0].split('",')
+    avg_ms = float(row[1].split(",")[2]) / 1e6
+    d = json.load(open(os.path.join(P, "r05_bench_line.json")))
+    leg = d["legs"]["rays_1e6"]
+    assert abs(avg_ms - leg["end_state"]["kernel_ms"]) < 0.03 * avg_ms
+    assert leg["end_state"]["frac"] >= 0.40 and leg["end_state"]["kernel_ms"] <= 36.5 and leg["trajectories"]["frac"] >= 0.40
+    assert d["device_code_sha256"] == sha and d["roofline"]["traffic"] is not None and 0.30 < d["roofline"]["frac"] < 0.34
+    assert set(d["legs"]) == {"flatearth_default", "range_dependent", "rays_1e6", "api", "api_config2", "fma_contracted"}
+    fma = d["legs"]["fma_contracted"]
+    assert "FMA contraction" in fma["build"] and fma["device_code_sha256"] != sha and "NOT the reference's arithmetic" in fma["note"]
+    assert fma["trajectories"]["kernel_ms"] < d["roofline"]["kernel_ms"]
+    assert all(g["rays_beyond_the_10x_rule"] == 0 and g["bounce_counts_equal"] for g in fma["against_the_reference"].values())
+    api2 = tr["api-config2"]
+    assert api2["blocked"]["fan_kernel_write_over_sample_bytes"] <= 1.25 < 2.0 < api2["rows"]["fan_kernel_write_over_sample_bytes"]
+    assert tr["sample-nosave@1000000"]["rays"] == 1_000_000
+    sq = tr["sample-nosave@1000000-sq_counters"]
+    assert sq["SQ_WAVES"] == 2048.0        # persistent: 256 workgroups x 8 waves, whatever the ray count
+    wt = json.load(open(os.path.join(P, "r05_wave_times.json")))
+    st, pe = wt["rays_1e6_static_deal_of_whole_workgroups"], wt["rays_1e6_persistent_waves"]
+    assert st["slot_time_split"]["idle_inside_a_resident_workgroup"] > 0.15 and pe["simd_residency"]["two_or_more_waves"] > 0.93
+    svc = json.load(open(os.path.join(P, "r05_service_times.json")))
+    assert 15e3 < svc["end_state"]["cycles_per_service"] < 25e3 and len(svc["end_state"]["sections"]) == 18
+    log = open(os.path.join(P, "r05_bitparity_S1001.txt")).read()
+    assert log.count("all 1001 samples (SciPy order) 1.00000") == 9 and log.count("bit-equal True") >= 3 and "0.99" not in log.split("default sample")[0]
+    log6 = open(os.path.join(P, "r05_bitparity_1e6_rays.txt")).read()
+    assert "rays 1000000" in log6 and log6.count("all 11 samples (SciPy order) 1.00000") == 3 and "n=999535" in log6
+    b = json.load(open(os.path.join(P, "r05_isa_budget.json")))
+    assert b["device_code_sha256"] == sha and 600 < b["derived"]["headline"]["per_wave_trip"]["SQ_INSTS_VALU"] < 800
+    reh = json.load(open(os.path.join(P, "r05_bench_line_5ranks_one_gpu_rehearsal.json")))
+    c4 = reh["legs"]["config4"]
+    assert reh["ranks_joined"] == 5 and c4["gathered_rays"] == 5_000_000 and c4["histogram_counted_rays"] == c4["gathered_ok"]
+    assert len(c4["roofline_per_gpu"]["ranks"]) == 5 and all(q["kernel_ms"] > 0 and q["frac"] > 0 for q in c4["roofline_per_gpu"]["ranks"])
+    assert reh["eigenray_sharded"]["fan_rays_per_gpu"] == 200_000 and "REHEARSAL" in reh["config"]["sharding"]
+
+
 def test_eval_cache_fingerprint_is_cheap_and_sees_in_place_edits():
     """host_physics._fingerprint (the content check of the tables kept on the device for point-by-point derivsrd / event
     calls): whole-array hashes up to 1 MB, a strided sample beyond -- an in-place edit of a whole table, of a row, of a
