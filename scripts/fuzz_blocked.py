@@ -27,5 +27,26 @@ for seed in range(20000, 20600):
     ok = all(np.array_equal(a, b, equal_nan=True) for a, b in zip(*outs))
     if not ok:
         print("MISMATCH seed", seed, desc); sys.exit(1)
+    # the host-pointer entry (what API callers get): sample-blocked kernel + un-blocking pass against plain rows, with and
+    # without the compaction of dropped rays, and a fan handle's fetches
+    for compact in (False, True):
+        res = []
+        for api_blocked in (0, 1):
+            env.set_option("api_blocked", api_blocked)
+            res.append(env.shoot_fan(y0, kw["x0"], kw["x1"], kw["S"], rtol=kw["rtol"], terminate_backwards=kw["terminate_backwards"],
+                                     sample_major=True, stored_sign=True, compact=compact))
+        for k in ("T", "z", "p", "end", "status", "n_bott", "n_surf", "n_steps", "n_rej"):
+            if not (res[0][k].shape == res[1][k].shape and np.array_equal(res[0][k], res[1][k], equal_nan=True)):
+                print("API MISMATCH seed", seed, desc, "compact", compact, k); sys.exit(1)
+        if not compact and not all(np.array_equal(res[1][k], -o if k in "zp" else o, equal_nan=True) for k, o in zip("Tzp", outs[0][:3])):
+            print("API vs device MISMATCH seed", seed, desc); sys.exit(1)
+    h = _lib.FanHandle(env, kw["x0"], kw["x1"], kw["S"], y0=y0, rtol=kw["rtol"], terminate_backwards=kw["terminate_backwards"], stored_sign=True)
+    full = h.fetch_samples(compact=False)
+    ref_full = env.shoot_fan(y0, kw["x0"], kw["x1"], kw["S"], rtol=kw["rtol"], terminate_backwards=kw["terminate_backwards"],
+                             sample_major=True, stored_sign=True)
+    if not all(np.array_equal(full[k], ref_full[k], equal_nan=True) for k in "Tzp"):
+        print("FAN HANDLE MISMATCH seed", seed, desc); sys.exit(1)
+    h.close()
     env.close()
-print(f"{n_env} random environments, {n_hbm} on the HBM-table path: blocked layout == row layout on every ray and sample")
+print(f"{n_env} random environments, {n_hbm} on the HBM-table path: blocked layout == row layout on every ray and sample "
+      "(device entry, host entry with and without compaction, fan handle)")
