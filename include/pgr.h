@@ -256,9 +256,11 @@ int pgr_arrival_histogram_device(int device, const double* t_end, int64_t t_stri
  *                            issue priorities by cost quartile; 1 = priorities only; 0 = strided deal
  *   PGR_OPT_PERSISTENT       fans of several rounds (more 64-ray packets than the chip holds waves): a = 1 (default)
  *                            one workgroup per CU whose waves claim packet after packet from the cost-sorted list
- *                            (most expensive first) with one atomic each; a = 0 the static deal of whole
- *                            cost-sorted workgroups (what replaces the reference's pool.imap over single rays,
- *                            REF/launch_rays.py:157-164, either way)
+ *                            (most expensive first) with one atomic each -- in fans of up to two rounds the first
+ *                            packet of a workgroup's waves 4 .. 7 (the SIMD partners of waves 0 .. 3) comes from the
+ *                            list's cheap end, so that every steep packet starts beside a cheap one; a = 2 / 3 never /
+ *                            always so; a = 0 the static deal of whole cost-sorted workgroups (what replaces the
+ *                            reference's pool.imap over single rays, REF/launch_rays.py:157-164, either way)
  *   PGR_OPT_API_BLOCKED      pgr_shoot_fan (sample-major) and pgr_fan_launch on environments whose tables stay in HBM / L2:
  *                            a = 1 (default) the trajectories are integrated by the sample-blocked kernel
  *                            (PGR_SAMPLE_BLOCKED: full 32-byte stores, 1.2x instead of 2.3x the sample bytes written) and

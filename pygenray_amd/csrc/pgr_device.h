@@ -96,6 +96,7 @@ struct FanArgs {
     // first; a wave claims the next one with atomicAdd(wave_queue, 1) until the list is empty.  Null: one packet per wave.
     int* wave_queue;
     int n_queue;
+    int n_queue_tail;     // the last n_queue_tail entries are the FIRST packets of the workgroups' waves 4 .. 7 (4 per workgroup), not queued
 };
 
 // The fan kernel's service phase and epilogue re-read FanArgs from the kernel-argument segment (so that what only they

@@ -30,7 +30,7 @@ extern "C" int pgr_env_set_option(pgr_env* env, int what, int a, int b)
         env->api_blocked = a;
         return 0;
     case PGR_OPT_PERSISTENT:
-        if (a < 0 || a > 1) return fail("persistent: 0 = static deal of whole workgroups, 1 = persistent waves + packet queue");
+        if (a < 0 || a > 3) return fail("persistent: 0 = static deal of whole workgroups, 1 = persistent waves + packet queue (fans of up to two rounds: waves 4 .. 7 start at the list's cheap end), 2 = every packet from the list's head, 3 = waves 4 .. 7 always start at the cheap end");
         env->persistent = a;
         return 0;
     default:

@@ -69,6 +69,7 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
     // packets (the static mode 3) the SIMD slots of the waves that end early idle until then, and the chip drains
     // workgroup by workgroup at the end of the launch.  Which wave integrates a packet, and when, never changes what it
     // computes.  !PERSIST: the loop body runs once.
+    bool first_packet = true;
     for (;;) {
     // PERSIST: what is read at the start of a packet comes from the kernel-argument segment through a pointer the
     // compiler cannot trace back (as in the service phase and the epilogue): as ordinary arguments these values would
@@ -91,10 +92,22 @@ pgr_fan_kernel(const EnvDev* __restrict__ env_p, FanArgs a)
         // pace, the cheaper one fills the issue slots it leaves
         int slot = blockIdx.x * n_cw + wv;
         if (PERSIST && wave_queue) {
-            int got = 0;
-            if ((threadIdx.x & 63) == 0) got = atomicAdd(wave_queue, 1);
-            slot = __builtin_amdgcn_readfirstlane(got);
-            if (slot >= aq.n_queue) break;      // (wave-uniform: the list is empty, this wave is done)
+            // A SIMD's two resident waves are workgroup waves k and k + 4.  Straight down the list both would start on
+            // packets of the list's expensive head -- two steep packets on one SIMD take the sum of their lone times,
+            // and a fan of two or three rounds lasts as long as that pair (140 000 rays: 8.2 ms for 1.4 x the work of
+            // the 4.9 ms 1e5-ray fan).  So the FIRST packet of waves 4 .. 7 comes from the list's cheap END (entry
+            // n - 1 - (4 b + k - 4), no atomic), everything else from its head: each steep packet starts beside a cheap
+            // one and, with the higher issue priority, runs at nearly its lone pace.  (n_queue_tail = 4 x grid, or 0.)
+            const int n_tail = aq.n_queue_tail, n_head = aq.n_queue - n_tail;
+            if (first_packet && wv >= 4 && n_tail) {
+                slot = aq.n_queue - 1 - ((int)blockIdx.x * 4 + (wv - 4));
+            } else {
+                int got = 0;
+                if ((threadIdx.x & 63) == 0) got = atomicAdd(wave_queue, 1);
+                slot = __builtin_amdgcn_readfirstlane(got);
+                if (slot >= n_head) break;      // (wave-uniform: the list is empty, this wave is done)
+            }
+            first_packet = false;
         }
         int m = q_map[slot];
         gwave = (m < 0) ? -1 : (m & 0x0fffffff);

@@ -20,6 +20,7 @@ ap.add_argument("--S", type=int, default=1001)
 ap.add_argument("--lib", default=None)
 ap.add_argument("--place", type=int, default=-1)
 ap.add_argument("--park", type=int, nargs="*", default=[64, 10], help="pairs: lanes trips lanes trips ...")
+ap.add_argument("--persistent", type=int, default=-1)
 ap.add_argument("--exact", action="store_true")
 ap.add_argument("--exact-samples", action="store_true")
 a = ap.parse_args()
@@ -29,6 +30,8 @@ arrs = munk_arrays(a.km * 1e3, nr=(101 if a.slope else 100), sofar_slope=a.slope
 env = _lib.EnvHandle(*arrs)
 if a.place >= 0:
     env.set_option("placement", a.place)
+if a.persistent >= 0:
+    env.set_option("persistent", a.persistent)
 theta = np.linspace(a.amin, a.amax, a.rays)
 y0 = fan_y0(arrs, 1000.0, 0.0, -theta)
 for mode in a.modes:

@@ -1,5 +1,6 @@
-"""Persistent waves (PGR_OPT_PERSISTENT 1, the default for fans of several rounds) against the static deal of whole
-cost-sorted workgroups (0): every output array of every ray must hold the same bits -- which wave integrates a
+"""Persistent waves (PGR_OPT_PERSISTENT 1, the default for fans of several rounds; 2 / 3: every packet from the list's head /
+the SIMD partners' first packets from its cheap end, which 1 chooses between by the number of rounds) against the static
+deal of whole cost-sorted workgroups (0): every output array of every ray must hold the same bits -- which wave integrates a
 packet, and when, never changes what it computes -- and the kernel times of both.
 
 usage (GPU box): python scripts/persist_check.py [--lib x.so] [--quick]
@@ -31,6 +32,8 @@ def flat_earth(arrs):
 
 
 cases = [("configs[1] tables, 1e6 rays, end state only", munk_arrays(1000e3), 1_000_000, dict(save=False)),
+         ("configs[1] tables, 140k rays, end state only", munk_arrays(1000e3), 140_000, dict(save=False)),
+         ("configs[1] tables, 200k rays, S = 101 rows", munk_arrays(1000e3), 200_000, dict(save=True, S=101)),
          ("configs[1] tables, 300k rays, S = 101 rows", munk_arrays(1000e3), 300_000, dict(save=True, S=101)),
          ("configs[2] tables, 300k rays, end state only", munk_arrays(1000e3, nr=101, sofar_slope=2e-4), 300_000, dict(save=False)),
          ("configs[2] tables, 300k rays, S = 103 sample-blocked", munk_arrays(1000e3, nr=101, sofar_slope=2e-4), 300_000, dict(save=True, S=103, blocked=True)),
@@ -44,7 +47,7 @@ for name, arrs, n, kw in cases:
     env = _lib.EnvHandle(*arrs)
     y0 = fan_y0(arrs, 1000.0, 0.0, -np.linspace(-20, 20, n))
     outs, times = {}, {}
-    for mode in (0, 1):
+    for mode in (0, 1, 2, 3):
         env.set_option("persistent", mode)
         fan = DeviceFan(env, y0, 0.0, 1000e3, kw.get("S", 1), save=kw["save"], sample_major=True, sample_blocked=kw.get("blocked", False))
         fan.run(); torch.cuda.synchronize()
@@ -61,10 +64,10 @@ for name, arrs, n, kw in cases:
         outs[mode] = o
         steps = fan.ray_steps()
         del fan
-    diff = [k for k in outs[0] if not np.array_equal(outs[0][k], outs[1][k], equal_nan=True)]
+    diff = [(m, k) for m in (1, 2, 3) for k in outs[0] if not np.array_equal(outs[0][k], outs[m][k], equal_nan=True)]
     bad += len(diff)
-    r = {"case": name, "rays": n, "static_ms": times[0], "persistent_ms": times[1], "ray_steps": steps,
-         "arrays_that_differ": diff}
+    r = {"case": name, "rays": n, "static_ms": times[0], "persistent_ms": times[1], "persistent_all_from_the_head_ms": times[2], "persistent_partners_start_at_the_cheap_end_ms": times[3],
+         "ray_steps": steps, "arrays_that_differ": diff}
     res.append(r)
     print(json.dumps(r), flush=True)
     env.close()

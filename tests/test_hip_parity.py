@@ -1423,17 +1423,18 @@ def test_persistent_waves_hold_the_same_bits_as_the_static_deal(lib):
     eo = pr.OceanEnvironment2D(pr.DataArray(np.tile(pr.munk_ssp(z), (9, 1)), dims=["range", "depth"], coords={"range": r, "depth": z}),
                                pr.DataArray(np.full(9, 5000.0), dims=["range"], coords={"range": r}), flat_earth_transform=True)
     arrs_fe = _unpack_envi(eo, flatearth=True)
-    cases = [(arrs, 8 * cus * 64 + 65, 1, False, False), (arrs, 200_001, 7, True, False), (arrs_rd, 160_000, 1, False, False),
+    cases = [(arrs, 8 * cus * 64 + 65, 1, False, False), (arrs, 200_001, 7, True, False), (arrs, 16 * cus * 64 + 1, 1, False, False), (arrs_rd, 160_000, 1, False, False),
              (arrs_rd, 140_000, 10, True, True), (arrs_rd, 140_000, 9, True, False), (arrs_fe, 150_000, 5, True, False)]
     for arrs_, n, S, save, blocked in cases:
         env = lib.EnvHandle(*arrs_)
         y0 = y0_for(oracle, arrs_, 900.0, 0.0, np.linspace(-19.5, 19.5, n))
         env.set_option("persistent", 0)
         ref = run(env, y0, 80e3, S, save, blocked)
-        env.set_option("persistent", 1)
-        got = run(env, y0, 80e3, S, save, blocked)
-        for k in ref:
-            assert np.array_equal(got[k], ref[k], equal_nan=True), (n, S, blocked, k)
+        for mode in (2, 3, 1):     # every packet from the list's head / waves 4 .. 7 start at its cheap end / the default rule
+            env.set_option("persistent", mode)
+            got = run(env, y0, 80e3, S, save, blocked)
+            for k in ref:
+                assert np.array_equal(got[k], ref[k], equal_nan=True), (n, S, blocked, k, mode)
         env.set_option("placement", 0)
         plain = run(env, y0, 80e3, S, save, blocked)
         for k in ref:
