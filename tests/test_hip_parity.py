@@ -1234,6 +1234,40 @@ def test_many_fans_in_flight_on_user_streams_keep_their_wave_maps(lib):
     env.close()
 
 
+def test_persistent_fans_in_flight_on_user_streams_keep_their_packet_queues(lib):
+    """Four fans of more than one round -- persistent waves, each launch with its own cost-sorted list and its own queue counter
+    in device memory -- in flight at once on four user streams of ONE environment (an LDS-table and an HBM-table one):
+    every fan's result equals the one-at-a-time result, twice over (the slots are re-used by the second round)."""
+    import torch
+    from pygenray_amd.device_fan import DeviceFan, fan_y0
+    for arrs in (munk_arrays(60e3, nr=12), munk_arrays(60e3, nr=13, sofar_slope=1e-3)):
+        env = lib.EnvHandle(*arrs)
+        fans, streams = [], []
+        for k in range(4):
+            n = 135_000 + 40_000 * k      # 2110 .. 3985 packets: one to two rounds (the cheap-end rule) -- and, last, beyond
+            y0 = fan_y0(arrs, 900.0, 0.0, -np.linspace(-19.5 + 0.1 * k, 19.5, n))
+            fans.append(DeviceFan(env, y0, 0.0, 60e3, 1, save=False))
+            streams.append(torch.cuda.Stream())
+        y0 = fan_y0(arrs, 900.0, 0.0, -np.linspace(-19.5, 19.5, 300_000))
+        fans.append(DeviceFan(env, y0, 0.0, 60e3, 1, save=False)); streams.append(torch.cuda.Stream())
+        ref = []
+        for f in fans:
+            f.run()
+            torch.cuda.synchronize()
+            ref.append((f.end.clone(), f.n_steps.clone(), f.status.clone()))
+            f.end.zero_(); f.n_steps.zero_(); f.status.fill_(-7)
+        torch.cuda.synchronize()
+        for rep in range(2):
+            for f, st in zip(fans, streams):
+                with torch.cuda.stream(st):
+                    f.run()
+            torch.cuda.synchronize()
+            for f, (e, ns_, s_) in zip(fans, ref):
+                assert torch.equal(torch.nan_to_num(f.end), torch.nan_to_num(e)) and torch.equal(f.n_steps, ns_) and torch.equal(f.status, s_)
+                f.end.zero_(); f.n_steps.zero_(); f.status.fill_(-7)
+        env.close()
+
+
 _TWO_RANK_WORKER = r"""
 import os, sys
 sys.path.insert(0, %(root)r)
