@@ -17,7 +17,10 @@ def rss_mb():
 
 
 z = np.arange(0, 6000, 1.0); r = np.linspace(0, 300e3, 60)
-mk = lambda: pr.OceanEnvironment2D(pr.DataArray(np.tile(pr.munk_ssp(z), (60, 1)), dims=["range", "depth"], coords={"range": r, "depth": z}),
+# argv[2] = "rd": a range-dependent environment (tables in HBM / L2: the API's sample-blocked kernel + un-blocking pass)
+RD = len(sys.argv) > 2 and sys.argv[2] == "rd"
+ssp = (lambda: np.array([pr.munk_ssp(z, 1300.0 + 2e-4 * ri) for ri in r])) if RD else (lambda: np.tile(pr.munk_ssp(z), (60, 1)))
+mk = lambda: pr.OceanEnvironment2D(pr.DataArray(ssp(), dims=["range", "depth"], coords={"range": r, "depth": z}),
                                    pr.DataArray(np.full(60, 5000.0), dims=["range"], coords={"range": r}), flat_earth_transform=False)
 ang = np.linspace(-18, 18, 20_000)
 env = mk()
