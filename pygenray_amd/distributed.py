@@ -234,6 +234,28 @@ def shoot_rays_sharded(source_depth, source_range, launch_angles, receiver_range
     return fan
 
 
+def _collective_device(group=None):
+    """Where the tensors of a collective on `group` live: RCCL ("nccl") moves device memory, gloo host memory."""
+    if dist.is_available() and dist.is_initialized() and "nccl" in str(dist.get_backend(group)):
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def _all_gather_rows(local, group=None):
+    """All-gather one float64 array of the SAME shape on every rank -> ndarray [world, *shape] (one
+    ``all_gather_into_tensor``; without an initialised process group: the array itself, world = 1)."""
+    local = np.ascontiguousarray(local, dtype=np.float64)
+    rank, world = _rank_world(group)
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
+        return local[None]
+    dev = _collective_device(group)
+    send = torch.from_numpy(local).to(dev)
+    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=torch.float64, device=dev)
+    if send.numel():      # (the shape is the same on every rank, so every rank takes the same branch)
+        dist.all_gather_into_tensor(out, send, group=group)
+    return out.view((world,) + tuple(local.shape)).cpu().numpy()
+
+
 def find_eigenrays_sharded(rays, receiver_depths, source_depth, source_range, receiver_range, num_range_save,
                            environment, ztol=1, max_iter=20, group=None, refine=None, **kwargs):
     """``find_eigenrays`` over all ranks of `group` (REF/eigenrays.py:11-203).  `rays` is the gathered fan
@@ -256,31 +278,52 @@ def find_eigenrays_sharded(rays, receiver_depths, source_depth, source_range, re
                                        num_range_save, environment, ztol, max_iter, kwargs)
 
     def refine_dealt(z1s, z2s, th1s, th2s, receiver_depth):
+        # Bracket k belongs to rank k mod world -- every rank knows every rank's share, so only RESULTS travel, as two
+        # tensor collectives of fixed-shape float64 records (no pickled objects: under "nccl" an object gather is bytes
+        # through device tensors plus a size exchange per rank):
+        #   1. [n_pad, 4] per rank = (found, launch angle, n_bott, n_surf) of its brackets, n_pad = ceil(nbk / world);
+        #   2. [f_max, 3, S] per rank = (T, z, p) of the eigenrays it found, f_max = the largest per-rank count (known to
+        #      everybody from 1.), plus one row for the save grid.
         nbk = len(z1s)
+        n_pad = (nbk + world - 1) // world
         mine = np.arange(rank, nbk, world)
+        rec = np.zeros((n_pad, 4))
+        Tm = Zm = Pm = np.zeros((0, S))
+        r = np.linspace(source_range, receiver_range, S)
         if len(mine):
             rd_m = np.asarray(receiver_depth)[mine] if np.ndim(receiver_depth) else receiver_depth
-            found, th, r, T, Z, P, nb, ns = refine(z1s[mine], z2s[mine], th1s[mine], th2s[mine], rd_m)
-            part = (mine, np.asarray(found), np.asarray(th), np.asarray(r), T[found], Z[found], P[found],
-                    np.asarray(nb)[found], np.asarray(ns)[found])
-        else:
-            part = (mine, np.zeros(0, bool), np.zeros(0), None, np.zeros((0, S)), np.zeros((0, S)), np.zeros((0, S)),
-                    np.zeros(0, np.int64), np.zeros(0, np.int64))
-        parts = [part]
-        if world > 1:
-            parts = [None] * world
-            dist.all_gather_object(parts, part, group=group)
+            found_m, th_m, r_m, T_m, Z_m, P_m, nb_m, ns_m = refine(z1s[mine], z2s[mine], th1s[mine], th2s[mine], rd_m)
+            found_m = np.asarray(found_m, bool)
+            rec[:len(mine), 0] = found_m
+            rec[:len(mine), 1] = np.asarray(th_m, float)
+            rec[:len(mine), 2] = np.asarray(nb_m, float)      # (bounce counts: exact in a double)
+            rec[:len(mine), 3] = np.asarray(ns_m, float)
+            Tm, Zm, Pm = np.asarray(T_m)[found_m], np.asarray(Z_m)[found_m], np.asarray(P_m)[found_m]
+            if r_m is not None:
+                r = np.asarray(r_m, float)
+        recs = _all_gather_rows(rec, group)                              # [world, n_pad, 4]
+        n_found = (recs[:, :, 0] != 0).sum(axis=1)
+        f_max = int(n_found.max()) if world else 0
+        pay = np.zeros((f_max * 3 + 1, S))
+        nf = len(Tm)
+        pay[0:nf], pay[f_max:f_max + nf], pay[2 * f_max:2 * f_max + nf] = Tm, Zm, Pm
+        pay[3 * f_max] = r
+        pays = _all_gather_rows(pay, group)                              # [world, 3 f_max + 1, S]
         found = np.zeros(nbk, bool); th = np.zeros(nbk)
         T = np.zeros((nbk, S)); Z = np.zeros((nbk, S)); P = np.zeros((nbk, S))
         nb = np.zeros(nbk, np.int64); ns = np.zeros(nbk, np.int64)
-        r = np.linspace(source_range, receiver_range, S)
-        for (m, f, t_, r_, T_, Z_, P_, nb_, ns_) in parts:
+        for q in range(world):
+            m = np.arange(q, nbk, world)
+            f = recs[q, :len(m), 0] != 0
             found[m] = f
-            th[m] = t_
+            th[m] = recs[q, :len(m), 1]
             hit = m[f]
-            T[hit], Z[hit], P[hit], nb[hit], ns[hit] = T_, Z_, P_, nb_, ns_
-            if r_ is not None and len(hit):
-                r = r_
+            nb[hit] = np.rint(recs[q, :len(m), 2][f]).astype(np.int64)
+            ns[hit] = np.rint(recs[q, :len(m), 3][f]).astype(np.int64)
+            k = len(hit)
+            T[hit], Z[hit], P[hit] = pays[q, 0:k], pays[q, f_max:f_max + k], pays[q, 2 * f_max:2 * f_max + k]
+            if k:
+                r = pays[q, 3 * f_max]
         return found, th, r, T, Z, P, nb, ns
 
     return _find_eigenrays(rays, receiver_depths, source_depth, S, environment, refine_dealt, together=together)

@@ -51,10 +51,17 @@ def _fingerprint(arrs):
     """Content of the tables: the reference's functions are pure functions of their array arguments, so a caller that
     edits a table in place (cin += dc in a sensitivity loop) must not be served from the tables uploaded before the
     edit.  The reference calls its event functions point by point, so this runs per scalar query and has to be cheap:
-    arrays up to 1 MB are hashed whole (crc32); of a larger one (tens of MB of cin / cpin) shape, dtype and a strided
-    sample of 65 536 elements that always includes the first and the last -- every edit of a whole table or of a whole
-    row / column is seen, an edit of single elements of a large table may not be: call ``clear_eval_cache()`` after
-    such an edit.  No copy is made of an array that is float64 and C-contiguous already."""
+    arrays up to 1 MB are hashed whole (crc32).  Of a larger one (tens of MB of cin / cpin): shape, dtype and
+      * its first, middle and last ROW (a whole-column edit changes every row, so all three) and its first, middle and
+        last COLUMN (a whole-row edit changes every column) -- every edit of a whole row or a whole column of a 2-D table
+        is seen whatever the shape (a flat strided sample alone is not enough: a step that shares a factor with the
+        row length only ever visits the columns that are multiples of it -- 300 x 6000 gave step 27 and never saw
+        column 4321);
+      * a flat strided sample of ~65 536 elements whose step is coprime with the row length (it walks through every
+        column residue) and which always includes the first and the last element.
+    An edit of single elements of a large table may still be missed: call ``clear_eval_cache()`` after such an edit.  No
+    copy is made of an array that is float64 and C-contiguous already."""
+    import math
     import zlib
     out = []
     for a in arrs:
@@ -64,9 +71,17 @@ def _fingerprint(arrs):
             out.append((a.shape, zlib.crc32(b)))
         else:
             flat = a.reshape(-1) if a.flags.c_contiguous else a.ravel()
-            step = max(1, flat.size // 65536) | 1          # odd: walks through every column of a 2-D table
-            out.append((a.shape, str(a.dtype), zlib.crc32(np.ascontiguousarray(flat[::step])),
-                        float(flat[0]), float(flat[-1])))
+            ncols = a.shape[-1] if a.ndim >= 1 else 1
+            step = max(1, flat.size // 65536) | 1
+            while math.gcd(step, ncols) != 1:                # odd and coprime with the row length
+                step += 2
+            parts = [zlib.crc32(np.ascontiguousarray(flat[::step]))]
+            if a.ndim >= 2:
+                m = flat.reshape(-1, ncols)                  # (a view of the contiguous data)
+                nrow = m.shape[0]
+                parts.append(zlib.crc32(np.ascontiguousarray(m[[0, nrow // 2, nrow - 1], :])))
+                parts.append(zlib.crc32(np.ascontiguousarray(m[:, [0, ncols // 2, ncols - 1]])))
+            out.append((a.shape, str(a.dtype), tuple(parts), float(flat[0]), float(flat[-1])))
     return tuple(out)
 
 

@@ -352,19 +352,24 @@ def refine(z1s, z2s, th1s, th2s, rd):                # REF/eigenrays.py:206-268,
 
 def run(tag):
     fan, raw = shoot_rays_sharded(ZS, 0.0, theta, X1, env, flatearth=False, compute=compute, return_all=True)
-    er = find_eigenrays_sharded(fan, [1000.0, 2500.0], ZS, 0.0, X1, S, env, refine=refine)
+    er = find_eigenrays_sharded(fan, [1000.0, 2500.0, 70.0], ZS, 0.0, X1, S, env, refine=refine)
     h, edges = arrival_histogram_sharded(ZS, 0.0, theta, X1, env, 32, 39.0, 41.0, flatearth=False, compute=compute)
     out = dict(status=raw["status"], thetas=fan.thetas, ts=fan.ts, zs=fan.zs, ps=fan.ps, nb=fan.n_botts, hist=h, edges=edges)
-    for k in (0, 1):
+    for k in (0, 1, 2):
         out[f"e{k}_th"] = er.launch_angles[k]; out[f"e{k}_ts"] = er.ts[k]; out[f"e{k}_zs"] = er.zs[k]
         out[f"e{k}_nb"] = er.n_botts[k]; out[f"e{k}_ra"] = er.received_angles[k]
         out[f"e{k}_failed"] = np.array(er.failed_eray_theta_brackets[k], dtype=float).reshape(-1, 2)
-        out[f"e{k}_n"] = np.array([er.num_eigenrays[[1000.0, 2500.0][k]], er.num_eigenrays_found[k]])
+        out[f"e{k}_n"] = np.array([er.num_eigenrays[[1000.0, 2500.0, 70.0][k]], er.num_eigenrays_found[k]])
     np.savez(tag, **out)
 """
 
 _SHARD_WORKER = _SHARD_COMMON + r"""
-dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=int(sys.argv[1]), world_size=2)
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=int(sys.argv[1]), world_size=%(world)d)
+if %(world)d > 2:
+    # no pickled objects on the wire: the eigenray results travel as fixed-shape tensor collectives
+    def _no_objects(*a, **k):
+        raise AssertionError("all_gather_object used")
+    dist.all_gather_object = _no_objects
 run(sys.argv[2])
 dist.barrier(); dist.destroy_process_group()
 print("RANK_OK")
@@ -376,18 +381,21 @@ print("SINGLE_OK")
 """
 
 
-def test_sharded_shoot_eigenrays_histogram_gloo_world2_equals_single_process(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_shoot_eigenrays_histogram_gloo_equals_single_process(tmp_path, world):
     """pygenray_amd.distributed's API (shoot_rays_sharded -> find_eigenrays_sharded, arrival_histogram_sharded) on two
     gloo ranks against the very same calls in one process without torch.distributed: every rank must hold the
     single-process fan (launch order, dropped rays gone), the same EigenRays -- brackets straddle the two ranks' rays
     (with a strided deal EVERY bracket does) and one spans the rays a seamount drops in the middle of the fan --
-    and the same histogram.  The oracle stands in for the HIP fan and for the device refinement (CPU-only box)."""
+    and the same histogram.  The oracle stands in for the HIP fan and for the device refinement (CPU-only box).
+    world 4: uneven shards (77 rays: 20 / 19 / 19 / 19), a receiver depth with fewer brackets than ranks (ranks with ZERO
+    brackets still join both collectives), dropped rays on every rank's shard, and no ``all_gather_object`` anywhere."""
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    w = tmp_path / "worker.py"; w.write_text(_SHARD_WORKER % dict(root=ROOT, port=port))
+    w = tmp_path / "worker.py"; w.write_text(_SHARD_WORKER % dict(root=ROOT, port=port, world=world))
     one = tmp_path / "single.py"; one.write_text(_SHARD_SINGLE % dict(root=ROOT))
     procs = [subprocess.Popen([sys.executable, str(w), str(r), str(tmp_path / f"rank{r}.npz")], stdout=subprocess.PIPE,
-                              stderr=subprocess.PIPE, text=True) for r in range(2)]
+                              stderr=subprocess.PIPE, text=True) for r in range(world)]
     p1 = subprocess.run([sys.executable, str(one), str(tmp_path / "single.npz")], capture_output=True, text=True, timeout=600)
     assert p1.returncode == 0 and "SINGLE_OK" in p1.stdout, p1.stderr[-2000:]
     outs = [p.communicate(timeout=600) for p in procs]
@@ -405,7 +413,11 @@ def test_sharded_shoot_eigenrays_histogram_gloo_world2_equals_single_process(tmp
     spans = [rd for rd in (1000.0, 2500.0) if np.intersect1d(np.where(np.diff(np.sign(ref["zs"][:, -1] + rd)))[0], gap).size]
     assert spans, "no bracket spans the dropped rays"
     assert ref["hist"].sum() > 0.5 * (st == 0).sum()
-    for r in range(2):
+    if world == 4:
+        assert len(st) % 4 != 0 and 0 < ref["e2_n"][0] < 4          # uneven shards; ranks without a bracket at 70 m
+        for q in range(4):
+            assert (st[q::4] != 0).any()                              # every shard holds dropped rays
+    for r in range(world):
         got = np.load(tmp_path / f"rank{r}.npz")
         assert sorted(got.files) == sorted(ref.files)
         for k in ref.files:
@@ -681,6 +693,29 @@ def test_eval_cache_fingerprint_is_cheap_and_sees_in_place_edits():
         f1 = _fingerprint(big)
         assert f1 != f0
         f0 = f1
+    # whole-row and whole-column edits for shapes whose flat sampling step shares a factor with the row length
+    # (300 x 6000: step 27, gcd 3 -- the round-5 sample never visited column 4321), few wide rows, many narrow rows,
+    # a 3-D table, a non-contiguous (transposed) view
+    shapes = [(300, 6000), (101, 5001), (3, 200001), (200001, 3), (150000, 10), (50, 40, 300)]
+    for shp in shapes:
+        a = rng.normal(size=shp)
+        ncols, nrows = shp[-1], int(np.prod(shp[:-1]))
+        m = a.reshape(nrows, ncols)
+        g0 = _fingerprint([a])
+        for col in sorted({1, ncols // 3, (4321 % ncols), ncols - 2}):
+            m[:, col] += 1e-9
+            g1 = _fingerprint([a])
+            assert g1 != g0, (shp, "column", col)
+            g0 = g1
+        for row in sorted({1, nrows // 3, nrows - 2, 2 % nrows}):
+            m[row, :] += 1e-9
+            g1 = _fingerprint([a])
+            assert g1 != g0, (shp, "row", row)
+            g0 = g1
+    at = rng.normal(size=(6000, 300)).T            # (300, 6000), Fortran order
+    g0 = _fingerprint([at])
+    at[:, 4321] += 1e-9
+    assert _fingerprint([at]) != g0
     t0 = time.perf_counter()
     for _ in range(20):
         _fingerprint(big)
