@@ -13,7 +13,27 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libpgr_hip.so")
+REFERENCE_LIB = os.path.join(CSRC, "libpgr_hip.so")
+CONTRACTED_LIB = os.path.join(CSRC, "libpgr_hip_fma.so")
+CONTRACTED_FLAGS = ["-DPGR_FMA", "-ffp-contract=fast"]
+
+
+class PgrError(RuntimeError):
+    pass
+
+
+# Which arithmetic this PROCESS computes in -- an import-time choice, one library per process:
+#   PGR_ARITH=reference (default)  libpgr_hip.so: the reference's IEEE operations in the reference's order, correctly
+#                                  rounded div / sqrt / pow / asin / sin -- bit-identical to the CPU oracle; every parity
+#                                  statement of this package is about THIS build;
+#   PGR_ARITH=contracted           libpgr_hip_fma.so: the same sources with FMA contraction allowed (a*b + c fused, 2-ulp
+#                                  reciprocal square root): ~10 % faster, statistically as close to pygenray as pygenray is
+#                                  to itself (its numba kernels are fastmath=True, REF/integration_processes.py:26, and
+#                                  SciPy's stage sums run through BLAS), but NOT the oracle's bits: no bit-parity claim.
+ARITH = os.environ.get("PGR_ARITH", "reference").strip().lower() or "reference"
+if ARITH not in ("reference", "contracted"):
+    raise PgrError(f"PGR_ARITH={ARITH!r}: expected 'reference' (default) or 'contracted'")
+LIB_PATH = CONTRACTED_LIB if ARITH == "contracted" else REFERENCE_LIB
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -disable-machine-licm: the bounce code's asin / sin / pow are inlined polynomials; machine LICM
 # hoists their ~60 fp64 coefficients out of the WHOLE step loop into registers (235-256 VGPRs, 140-170
@@ -50,10 +70,6 @@ _i64 = ctypes.c_int64
 _vp = ctypes.c_void_p
 
 _lib = None
-
-
-class PgrError(RuntimeError):
-    pass
 
 
 def _llvm_bin():
@@ -130,6 +146,8 @@ def build(force=False, verbose=False, out=None, extra_flags=()):
     somewhere else (A/B experiments, scripts/kbench.py --lib); the default builds the product."""
     import shutil
     import tempfile
+    if out is None and ARITH == "contracted" and not extra_flags:
+        extra_flags = CONTRACTED_FLAGS      # (PGR_ARITH=contracted: `build()` builds the library this process loads)
     LIB_PATH = out or globals()["LIB_PATH"]
     src = os.path.join(CSRC, "pgr_hip.hip")
     hdr = os.path.join(_HERE, "..", "include", "pgr.h")
@@ -163,6 +181,11 @@ def build(force=False, verbose=False, out=None, extra_flags=()):
     return LIB_PATH
 
 
+def build_contracted(force=False, verbose=False):
+    """The PGR_ARITH=contracted library (libpgr_hip_fma.so) beside the product: same sources, FMA contraction allowed."""
+    return build(force=force, verbose=verbose, out=CONTRACTED_LIB, extra_flags=CONTRACTED_FLAGS)
+
+
 def _preload_torch_hip_runtime():
     """PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).  Two
     HIP runtimes in one process do not work (the second one finds no GPUs, and a torch stream
@@ -189,8 +212,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise PgrError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run "
-            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
-            "pygenray_amd has no CPU fallback.")
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc"
+            + ("; PGR_ARITH=contracted loads the FMA-contracted variant, built by the same call or by "
+               "pygenray_amd._lib.build_contracted()" if ARITH == "contracted" else "") +
+            "). pygenray_amd has no CPU fallback.")
     L = ctypes.CDLL(LIB_PATH)
     L.pgr_last_error.restype = ctypes.c_char_p
     L.pgr_device_count.restype = ctypes.c_int

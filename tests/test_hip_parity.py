@@ -17,6 +17,8 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def lib():
     from pygenray_amd import _lib
+    if _lib.ARITH != "reference":
+        pytest.skip("bit parity is claimed for the reference arithmetic only (PGR_ARITH=contracted: tests/test_contracted_arith.py)")
     _lib.load()
     assert _lib.device_count() >= 1
     return _lib
@@ -62,13 +64,15 @@ def test_device_unit_vectors(lib):
 
 
 # ------------------------------------------------------------------ golden fans (reference outputs)
-def golden_check(lib, g, arrs, x0, x1, S, prefix="", label="", abs_floor=None, strict_bouncing=True, **kw):
+def golden_check(lib, g, arrs, x0, x1, S, prefix="", label="", abs_floor=None, strict_bouncing=True, bit_parity=True, **kw):
     """HIP against vectors the REFERENCE itself produced (statistical policy (B) of helpers.py) and,
-    on the same inputs, against the oracle bit for bit (A)."""
+    on the same inputs, against the oracle bit for bit (A).  (`bit_parity=False`: rule (B) alone -- what
+    tests/test_contracted_arith.py asks of the PGR_ARITH=contracted library, which makes no bit-parity claim.)"""
     env = lib.EnvHandle(*arrs)
     out = env.shoot_fan(g[prefix + "y0"], x0, x1, S, exact_samples=True, **kw)
     o = oracle.shoot_fan(*arrs, g[prefix + "y0"], x0, x1, S, math=oracle.MATH_CR, **kw)
-    assert_bit_parity(out, o, label=label + " vs oracle")
+    if bit_parity:
+        assert_bit_parity(out, o, label=label + " vs oracle")
     ok = g[prefix + "ok"].astype(bool)
     ref = dict(T=g[prefix + "T"], z=g[prefix + "z"], p=g[prefix + "p"], n_bott=g[prefix + "n_bott"],
                n_surf=g[prefix + "n_surf"], status=np.where(ok, 0, -1), xi=o["xi"])

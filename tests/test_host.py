@@ -241,6 +241,30 @@ def test_no_cpu_fallback_and_oracle_not_imported_by_product(tmp_path):
             assert "import oracle" not in src and "from oracle" not in src, fn
 
 
+def test_arithmetic_mode_is_an_import_time_choice():
+    """PGR_ARITH (pygenray_amd/_lib.py): 'reference' by default, 'contracted' selects libpgr_hip_fma.so for the whole process,
+    anything else is refused at import; both libraries export the C ABI (no GPU needed for any of this)."""
+    import ctypes
+    code = "import sys; sys.path.insert(0, %r); import pygenray_amd as pr; from pygenray_amd import _lib; print(pr.ARITHMETIC, _lib.LIB_PATH)" % ROOT
+    for mode, lib_name in ((None, "libpgr_hip.so"), ("reference", "libpgr_hip.so"), ("contracted", "libpgr_hip_fma.so")):
+        env = {k: v for k, v in os.environ.items() if k != "PGR_ARITH"}
+        if mode:
+            env["PGR_ARITH"] = mode
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+        assert out.returncode == 0, out.stderr[-800:]
+        arith, path = out.stdout.split()
+        assert arith == (mode or "reference") and os.path.basename(path) == lib_name
+    bad = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, PGR_ARITH="fast"))
+    assert bad.returncode != 0 and "PGR_ARITH" in bad.stderr
+    from pygenray_amd import _lib
+    if os.path.exists(_lib.CONTRACTED_LIB):
+        L = ctypes.CDLL(_lib.CONTRACTED_LIB)
+        for sym in ("pgr_env_create", "pgr_shoot_fan", "pgr_shoot_fan_device", "pgr_fan_launch", "pgr_eigen_refine_depths_fn", "pgr_build_info"):
+            getattr(L, sym)
+        L.pgr_build_info.restype = ctypes.c_char_p
+        assert b"contract" in L.pgr_build_info().lower() or b"fma" in L.pgr_build_info().lower()
+
+
 # ---------------------------------------------------------------- multi-GPU path on gloo (world_size 2)
 _DIST_WORKER = r"""
 import os, sys
