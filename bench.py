@@ -260,6 +260,10 @@ def extra_legs():
         "end_state": kernel_leg(arrs1, 1_000_000, False, passes=3),
         # the headline's own kernel shape (S = 1001 trajectories, 24 GB of samples in HBM) at ten times its rays
         "trajectories": kernel_leg(arrs1, 1_000_000, True, passes=3)}
+    # the headline fan itself WITHOUT trajectories (end state only, B_alg = 80 B): the instance eigenray searches and
+    # histogram fans of this size run, and the number every end-state comparison of DESIGN.md refers to
+    legs["headline_end_state"] = dict(kernel_leg(arrs1, RAYS_PER_GPU, False),
+                                      workload="configs[1], 1e5 rays, 1000 km, end state only", kernel="pgr_fan_kernel<true, 4, 0, false>")
     lone = {"end_state": kernel_leg(arrs1, RAYS_PER_GPU, False, rays_lo=(0, 64)),
             "trajectories": kernel_leg(arrs1, RAYS_PER_GPU, True, rays_lo=(0, 64))}
     return legs, lone
@@ -666,6 +670,8 @@ def main(argv=None):
                                    f"(table in {'HBM/L2' if args.range_dependent else 'LDS'}, "
                                    f"{'non-uniform zin, cubic index estimate' if args.flat_earth else 'zin = j * 1 m'}, "
                                    f"{'linspace save grid' if save else 'end state only'})", "kernel_ms": kern_ms,
+                         # every timed step's own kernel time (HIP events on the launch stream): the mean above is over exactly these
+                         "kernel_ms_each": [round(a.elapsed_time(b), 4) for a, b in ev],
                          "bytes_per_ray_step": b_alg,
                          "note": "algorithmic bytes per SURVEY 8(d); the stepper keeps state in "
                                  "VGPRs and the SSP table in LDS, so it is fp64-VALU bound, not HBM bound"},

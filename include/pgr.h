@@ -112,7 +112,10 @@ void pgr_env_destroy(pgr_env* env);
 /* Properties the kernel selection depends on (for tests / diagnostics):
  * what = 0: tables range independent (all rows bitwise equal) ; 1: zin exactly uniform ;
  *        2: rin exactly uniform ; 3: LDS-resident table path selected ; 4: device index ;
- *        5 / 6 / 7: zin qualifies for the cubic index estimate / the quadratic one / the bin table. */
+ *        5 / 6 / 7: zin qualifies for the cubic index estimate / the quadratic one / the bin table ;
+ *        8: a sample-major trajectory fan of this environment is best written PGR_SAMPLE_BLOCKED (tables in HBM / L2, LDS left
+ *           for the staging, PGR_OPT_API_BLOCKED on): what pgr_shoot_fan / pgr_fan_launch do by themselves and what a
+ *           device-resident consumer of pgr_shoot_fan_device should ask for (the Python DeviceFan does by default). */
 int pgr_env_query(const pgr_env* env, int what);
 
 /* Shoot N rays: batched _shoot_ray_array + _interpolate_ray (REF/launch_rays.py:325-484,
@@ -215,7 +218,11 @@ int pgr_eigen_refine_depths(pgr_env* env, int64_t nbk, const double* th1, const 
  * a NaN) with the caller's own sine.  pygenray computes every initial slowness with NumPy's sine (REF/launch_rays.py:284-285),
  * which is faithful, not correctly rounded: the Python shim passes NumPy's here, so that a trial ray, the eigenray handed back and
  * shoot_ray(theta) of the same angle all start from the SAME bits, the reference's.  Costs one small D2H + H2D per iteration.
- * slowness == NULL: the device's correctly rounded sine, as pgr_eigen_refine_depths. */
+ * slowness == NULL: the device's correctly rounded sine, as pgr_eigen_refine_depths.
+ * The callback runs on the calling thread INSIDE the search: the environment's workspace lock is held and its buffers are in
+ * use, so it must NOT call back into the same pgr_env (pgr_shoot_fan, pgr_eigen_refine*, pgr_fan_*, pgr_env_destroy on `env`
+ * would deadlock or reallocate the workspace under the loop); other environments are fine.  It must not throw / longjmp
+ * through the C frames. */
 typedef void (*pgr_slowness_fn)(const double* ode_angles_deg, int64_t n, double* p0_out, void* user);
 int pgr_eigen_refine_depths_fn(pgr_env* env, int64_t nbk, const double* th1, const double* th2, const double* z1,
                                const double* z2, const double* receiver_depths, double source_depth, double source_range,
@@ -292,6 +299,14 @@ int pgr_debug_math(const double* a, const double* b, int64_t M, double* out9);
  * out[k] = { y_new[3], f_new[3], error_norm, 0.9 err**-0.2, f[3] }. */
 int pgr_debug_step(pgr_env* env, const double* t, const double* y, const double* h, int64_t M,
                    double rtol, double atol, double* out11);
+
+/* Which instance of the fan kernel the LAST pgr_shoot_fan_device on `env` launched, and how (tests: the instance walk of
+ * tests/test_hip_parity.py asserts that every instance it means to check is the one that ran):
+ * out = { LDS_TAB, ZM, SAVE, PERSIST, grid (workgroups), threads per workgroup, dynamic LDS bytes, pre-assigned queue tail };
+ * LDS_TAB: table in LDS (1) or HBM / L2 (0); ZM: depth look-up 0 division / binary search, 1 power-of-two dz, 2 bin table,
+ * 3 quadratic estimate + three nodes, 4 dz = 1, 5 cubic estimate; SAVE: 0 end state, 1 trajectories (linspace grid, default sample
+ * form), 2 any grid / PGR_EXACT_SAMPLES, 3 sample-blocked; PERSIST: persistent waves + packet queue.  -1s before any launch. */
+int pgr_debug_last_instance(const pgr_env* env, int32_t out[8]);
 
 /* What this build of the library is: whether the instruction-layout pass of the build was applied
  * ("relaid: 502 -> 31 straddles ..." or "plain hipcc") and which arithmetic variant was compiled.

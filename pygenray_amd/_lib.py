@@ -294,6 +294,12 @@ class EnvHandle:
     def lds_path(self):
         return bool(self.query(3))
 
+    @property
+    def blocked_layout(self):
+        """True when a sample-major trajectory fan of this environment is best written sample-blocked ([ceil(S/4)][N][4],
+        PGR_SAMPLE_BLOCKED): its tables stay in HBM / L2 and the LDS has room for the staging (include/pgr.h)."""
+        return bool(self.query(8))
+
     def close(self):
         if getattr(self, "_h", None):
             load().pgr_env_destroy(self._h)
@@ -374,7 +380,9 @@ class EnvHandle:
         """pgr_eigen_refine_depths_fn: the false-position loop of REF/eigenrays.py:206-268 for all brackets, on the device.
         `receiver_depth`: one depth for all brackets, or one per bracket (the brackets of several receiver depths
         searched together).  `slowness(ode_angles_deg) -> p0`: the caller's sin(radians(.)) / c for the trial rays (the shim
-        passes NumPy's, the reference's arithmetic); None: the device's correctly rounded sine."""
+        passes NumPy's, the reference's arithmetic); None: the device's correctly rounded sine.  The callback runs inside
+        the search with this environment's workspace lock held: it must not shoot rays or search on THIS EnvHandle
+        (include/pgr.h); plain NumPy arithmetic, as the shim's, is what it is for."""
         L = load()
         th1, th2, z1, z2 = (_c(a).reshape(-1) for a in (th1, th2, z1, z2))
         n = len(th1)
@@ -405,6 +413,15 @@ class EnvHandle:
         if failure:
             raise failure[0]
         return dict(theta=theta, state=state, n_trial=ntrial, z_end=zend, t_end=tend, launches=int(launches.value))
+
+    def last_instance(self):
+        """pgr_debug_last_instance: dict(lds_tab, zm, save, persist, blocks, threads, lds_bytes, queue_tail) of the last fan launch."""
+        L = load()
+        L.pgr_debug_last_instance.restype = ctypes.c_int
+        L.pgr_debug_last_instance.argtypes = [_vp, ctypes.POINTER(ctypes.c_int32)]
+        out = (ctypes.c_int32 * 8)()
+        check(L.pgr_debug_last_instance(self._h, out))
+        return dict(zip(("lds_tab", "zm", "save", "persist", "blocks", "threads", "lds_bytes", "queue_tail"), (int(v) for v in out)))
 
     def eval_points(self, x, y):
         x = _c(x); y = _c(y).reshape(-1, 3)

@@ -574,8 +574,15 @@ struct Ctx {
             // generic pointer: flat_load + a wait on both counters; it IS global memory)
             typedef double __attribute__((ext_vector_type(2))) d2v;
             typedef const d2v __attribute__((address_space(1))) * GlobalTab;
+#ifdef PGR_CELL_RECORDS
+            // (experiment, round 6: the four corner nodes of cell (i, j) as ONE 64-byte record -- one line per look-up instead
+            // of two pieces of two rows nz x 16 B apart; 4 x the table.  Measured, not kept: LABNOTES round 6)
+            const GlobalTab row = (GlobalTab)h_tab + ((size_t)i * (size_t)(h_nz - 1) + (size_t)j) * 4;
+            const d2v t00 = row[0], t01 = row[1], t10 = row[2], t11 = row[3];
+#else
             const GlobalTab row = (GlobalTab)h_tab + (size_t)i * h_row_stride + j;
             const d2v t00 = row[0], t01 = row[1], t10 = row[h_row_stride], t11 = row[h_row_stride + 1];
+#endif
             f.v00 = make_double2(t00.x, t00.y);
             f.v01 = make_double2(t01.x, t01.y);
             f.v10 = make_double2(t10.x, t10.y);

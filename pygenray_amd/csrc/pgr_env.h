@@ -281,6 +281,17 @@ extern "C" int pgr_env_create(pgr_env** out, int device, const double* cin, cons
     }
     EnvDev& d = e->d;
     int rc = 0;
+#ifdef PGR_CELL_RECORDS
+    if (!indep) {   // (experiment: {c, cp} of (i, j), (i, j + 1), (i + 1, j), (i + 1, j + 1) per cell, see Ctx::fetch_nodes)
+        std::vector<double2> rec((size_t)(nr - 1) * (size_t)(nz - 1) * 4);
+        for (int64_t i = 0; i + 1 < nr; i++)
+            for (int64_t j = 0; j + 1 < nz; j++) {
+                double2* q = &rec[((size_t)i * (size_t)(nz - 1) + (size_t)j) * 4];
+                q[0] = tab[i * nz + j]; q[1] = tab[i * nz + j + 1]; q[2] = tab[(i + 1) * nz + j]; q[3] = tab[(i + 1) * nz + j + 1];
+            }
+        tab.swap(rec);
+    }
+#endif
     rc |= upload(e, tab.data(), tab.size(), &d.tab);
     rc |= upload(e, rin, (size_t)nr, &d.rin);
     rc |= upload(e, zin, (size_t)nz, &d.zin);
@@ -380,6 +391,8 @@ extern "C" int pgr_env_create(pgr_env** out, int device, const double* cin, cons
     return 0;
 }
 
+static bool blocked_layout_fits(const pgr_env* env);   // (pgr_launch.h)
+
 extern "C" int pgr_env_query(const pgr_env* env, int what)
 {
     if (!env) return fail("null env");
@@ -392,6 +405,7 @@ extern "C" int pgr_env_query(const pgr_env* env, int what)
     case 5: return env->d.z_cubic;
     case 6: return env->d.z_quad;
     case 7: return env->d.z_bucket;
+    case 8: return blocked_layout_fits(env) ? 1 : 0;   // a trajectory fan of this environment would take the sample-blocked kernel (tables in HBM / L2, LDS left for the staging)
     default: return fail("pgr_env_query: unknown property");
     }
 }

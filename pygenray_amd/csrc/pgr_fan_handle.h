@@ -62,6 +62,11 @@ struct pgr_fan {
     hipEvent_t done = nullptr;
     std::vector<int32_t> status_host;
     std::vector<int> keep;
+    // un-blocking / compaction scratch of pgr_fan_fetch_samples: grow-only, kept for the next fetch of this fan (a fetch per
+    // array -- ts, then zs, then ps -- re-uses it) and freed with the handle: no hipMalloc / hipFree per fetch (hipFree waits
+    // for the whole device, i.e. for other fans in flight on other streams)
+    void* scratch = nullptr;
+    size_t scratch_bytes = 0;
     std::mutex m;
 };
 
@@ -71,6 +76,7 @@ extern "C" void pgr_fan_destroy(pgr_fan* f)
     pgr_env* env = f->env;
     (void)hipSetDevice(env->device);
     if (f->done) { (void)hipEventSynchronize(f->done); (void)hipEventDestroy(f->done); }
+    if (f->scratch) (void)hipFree(f->scratch);
     bool last = false;
     {
         std::lock_guard<std::mutex> lock(env->fan_pool_mutex);
@@ -289,7 +295,6 @@ extern "C" int pgr_fan_fetch_samples(pgr_fan* f, double* T, double* z, double* p
     if (z) { jobs.push_back({z, f->Z, ns_bytes}); src.push_back(f->Z); }
     if (p) { jobs.push_back({p, f->P, ns_bytes}); src.push_back(f->P); }
     if (jobs.empty()) return 0;
-    struct Tmp { std::vector<void*> p; ~Tmp() { for (void* q : p) if (q) (void)hipFree(q); } } tmp;
     hipStream_t st = f->stream;
     auto ready = [&](std::vector<D2HJob>& jb) -> int {
         int rc = fan_finish(f);
@@ -297,24 +302,28 @@ extern "C" int pgr_fan_fetch_samples(pgr_fan* f, double* T, double* z, double* p
         const bool squeeze = compact && f->M != f->N;
         if (!squeeze && !f->blocked) return 0;
         const int64_t M = squeeze ? f->M : f->N;
-        const size_t mbytes = (size_t)f->S * (size_t)M * sizeof(double);
+        const size_t mbytes = (size_t)f->S * (size_t)M * sizeof(double), piece = (mbytes + 255) & ~(size_t)255;
         if (M > 0) {
-            void* didx = nullptr;
+            const size_t need = jb.size() * piece + (((size_t)M * sizeof(int) + 255) & ~(size_t)255);
+            if (need > f->scratch_bytes) {
+                if (f->scratch) (void)hipFree(f->scratch);
+                f->scratch = nullptr; f->scratch_bytes = 0;
+                if (hipMalloc(&f->scratch, need) != hipSuccess) { f->scratch = nullptr; return fail("pgr_fan_fetch_samples: device allocation of the un-blocking scratch failed"); }
+                f->scratch_bytes = need;
+            }
+            int* didx = nullptr;
             if (squeeze) {
-                HIPCHK(hipMalloc(&didx, (size_t)M * sizeof(int)));
-                tmp.p.push_back(didx);
+                didx = (int*)((char*)f->scratch + jb.size() * piece);
                 HIPCHK(hipMemcpyAsync(didx, f->keep.data(), (size_t)M * sizeof(int), hipMemcpyHostToDevice, st));
             }
             for (size_t a3 = 0; a3 < jb.size(); a3++) {
-                void* t = nullptr;
-                HIPCHK(hipMalloc(&t, mbytes));
-                tmp.p.push_back(t);
+                double* t = (double*)((char*)f->scratch + a3 * piece);
                 if (f->blocked)
                     hipLaunchKernelGGL(pgr_unblock_cols, dim3((unsigned)((M + 255) / 256), (unsigned)((f->S + 3) / 4)), dim3(256), 0, st,
-                                       (const double*)jb[a3].src, (double*)t, (const int*)didx, M, f->N, (int)f->S);
+                                       (const double*)jb[a3].src, t, (const int*)didx, M, f->N, (int)f->S);
                 else
                     hipLaunchKernelGGL(pgr_gather_cols, dim3((unsigned)((M + 255) / 256), (unsigned)f->S), dim3(256), 0, st,
-                                       (const double*)jb[a3].src, (double*)t, (const int*)didx, M, f->N);
+                                       (const double*)jb[a3].src, t, (const int*)didx, M, f->N);
                 HIPCHK(hipGetLastError());
                 jb[a3].src = t;
             }

@@ -79,6 +79,9 @@ struct pgr_env {
     std::vector<void*> allocs;
     int num_cus = 256;
     size_t max_lds = 64 * 1024;
+    // the fan-kernel instance and launch shape of the LAST pgr_shoot_fan_device on this environment (pgr_debug_last_instance:
+    // the test that walks every instance asserts that it launched the one it meant to)
+    int last_instance[8] = {-1, -1, -1, -1, 0, 0, 0, 0};
 };
 
 extern "C" const char* pgr_last_error(void) { return g_err.c_str(); }
@@ -99,7 +102,7 @@ extern "C" const char* pgr_build_info(void)
         while (!t.empty() && t.back() == ' ') t.pop_back();
         info = "layout: " + t + "; arithmetic: ";
 #if defined(PGR_FMA)
-        info += "FMA contraction (experiments only)";
+        info += "FMA contraction allowed (the PGR_ARITH=contracted opt-in: NOT the reference's bits, no bit-parity claim)";
 #elif defined(PGR_STRICT)
         info += "compiler IEEE divide/sqrt";
 #else

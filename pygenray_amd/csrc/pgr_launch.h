@@ -256,8 +256,14 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
         if (at + need > env->max_lds) return fail("pgr_shoot_fan: no LDS left for PGR_SAMPLE_BLOCKED");
         a.blk_lds_off = (int)at; lds = at + need;
     }
+    // n_queue_tail = 4 x grid is only right for eight-wave workgroups on a grid of exactly `blocks` workgroups (the kernel reads
+    // tail entry n - 1 - (4 blockIdx + wave - 4) and never queues the tail): a change of either would skip or double-integrate packets
+    if (a.n_queue_tail && !(threads == 512 && blocks * 4 == (int64_t)a.n_queue_tail))
+        return fail("pgr_shoot_fan: internal error: the packet queue's pre-assigned tail does not match the launch shape");
 #define PGR_LAUNCH2(LT, ZMV, SV, PV)                                                                 \
     do {                                                                                             \
+        { const int li_[8] = {(int)(LT), (ZMV), (SV), (int)(PV), (int)blocks, threads, (int)lds, a.n_queue_tail};              \
+          for (int q_ = 0; q_ < 8; q_++) env->last_instance[q_] = li_[q_]; }                         \
         if (lds > 64 * 1024)                                                                         \
             HIPCHK(hipFuncSetAttribute((const void*)pgr_fan_kernel<LT, ZMV, SV, PV>,                 \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));       \
@@ -296,6 +302,13 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
     // and on every error return between the slot's pick and this point)
     guard.release();
     if (launch_err != hipSuccess) return fail(std::string("fan kernel launch: ") + hipGetErrorString(launch_err));
+    return 0;
+}
+
+extern "C" int pgr_debug_last_instance(const pgr_env* env, int32_t out[8])
+{
+    if (!env || !out) return fail("pgr_debug_last_instance: null argument");
+    for (int q = 0; q < 8; q++) out[q] = env->last_instance[q];
     return 0;
 }
 

@@ -260,7 +260,22 @@ extern "C" int pgr_shoot_fan(pgr_env* env, const double* y0, int64_t N, double s
     }
     // Environments whose tables stay in HBM / L2: the trajectories are integrated by the sample-blocked kernel (device
     // buffers [ceil(S/4)][N][4]) and un-blocked to the caller's [S][N] / [S][M] by the pass that squeezes dropped rays out
-    const bool blocked = save && lin && (flags & PGR_SAMPLE_MAJOR) && !(flags & PGR_EXACT_SAMPLES) && blocked_layout_fits(env);
+    bool blocked = save && lin && (flags & PGR_SAMPLE_MAJOR) && !(flags & PGR_EXACT_SAMPLES) && blocked_layout_fits(env) &&
+                   N <= 0x7fffffff;
+    if (blocked) {
+        // ... which needs a second workspace of 3 S N doubles beside the blocked buffers.  It is obtained HERE, before
+        // anything is launched: if the device cannot give it, the fan runs the plain row kernel straight into the
+        // caller's layout instead (same bits, 2.3 x the store traffic) -- the blocked path never fails a call that the row
+        // path would have served
+        const size_t piece = ((size_t)S * (size_t)N * sizeof(double) + 255) & ~(size_t)255;
+        const size_t need2 = 3 * piece + (((size_t)N * 4 + 255) & ~(size_t)255) + 256;
+        if (need2 > env->ws2_bytes) {
+            if (env->ws2) (void)hipFree(env->ws2);
+            env->ws2 = nullptr; env->ws2_bytes = 0;
+            if (hipMalloc(&env->ws2, need2) == hipSuccess) env->ws2_bytes = need2;
+            else { env->ws2 = nullptr; (void)hipGetLastError(); blocked = false; }
+        }
+    }
     const size_t dev_ns_bytes = blocked ? (size_t)N * (size_t)(4 * ((S + 3) / 4)) * sizeof(double) : ns_bytes;
     // carve one workspace: y0, r_save, T, Z, P, end, 5 int arrays (256-byte aligned pieces)
     const size_t sizes[11] = {(size_t)N * 24, (size_t)(save ? S : 1) * 8, dev_ns_bytes, dev_ns_bytes, dev_ns_bytes,
@@ -313,7 +328,7 @@ extern "C" int pgr_shoot_fan(pgr_env* env, const double* y0, int64_t N, double s
         const bool compact = save && (flags & PGR_COMPACT);
         if (!compact && !blocked) return 0;
         if (compact && !(flags & PGR_SAMPLE_MAJOR)) return fail("pgr_shoot_fan: PGR_COMPACT needs PGR_SAMPLE_MAJOR");
-        if (N > 0x7fffffff) return fail("pgr_shoot_fan: PGR_COMPACT supports at most 2^31 rays per call");
+        if (N > 0x7fffffff) return fail("pgr_shoot_fan: PGR_COMPACT supports at most 2^31 - 1 rays per call");   // (compact only: the blocked path was decided with N in range)
         int64_t M = N;
         if (compact) {
             keep.reserve((size_t)N);
@@ -326,7 +341,7 @@ extern "C" int pgr_shoot_fan(pgr_env* env, const double* y0, int64_t N, double s
         if (need2 > env->ws2_bytes) {
             if (env->ws2) (void)hipFree(env->ws2);
             env->ws2 = nullptr; env->ws2_bytes = 0;
-            if (hipMalloc(&env->ws2, need2) != hipSuccess) { env->ws2 = nullptr; return fail("pgr_shoot_fan: device allocation failed"); }
+            if (hipMalloc(&env->ws2, need2) != hipSuccess) { env->ws2 = nullptr; return fail("pgr_shoot_fan: device allocation of the PGR_COMPACT workspace failed"); }
             env->ws2_bytes = need2;
         }
         int* didx = (int*)((char*)env->ws2 + 3 * piece);

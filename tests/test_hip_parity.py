@@ -1487,6 +1487,80 @@ def test_persistent_waves_hold_the_same_bits_as_the_static_deal(lib):
         env.close()
 
 
+def test_every_kernel_instance_is_launched_and_bit_identical(lib, capsys):
+    """The library holds 72 instances of pgr_fan_kernel<LDS_TAB, ZM, SAVE, PERSIST> (csrc/pgr_launch.h: select_variant x sv x
+    persistent).  This walks ALL of them: for every (table home, depth look-up) an environment built to select it, for every
+    SAVE a fan shaped to need it, small fans for the one-packet-per-wave instances and fans of more packets than the chip
+    holds waves for the persistent ones -- each launch is confirmed by pgr_debug_last_instance to be the instance it was
+    meant to be, and checked against the oracle by rule (A): status, bounce counts, accepted AND rejected steps, end states,
+    samples (SAVE 2: every sample bit for bit; SAVE 1 / 3: bit-equal outside a step, 1e-12 inside)."""
+    import torch
+    import pygenray_amd as pr
+    from pygenray_amd.device_fan import DeviceFan
+    z1 = np.arange(0, 6000, 1.0)
+    depf = pr.eflat(z1, 35.0, pr.munk_ssp(z1))[0]               # the flat-earth image of a uniform grid: smooth, non-uniform
+    grids = {4: (z1, 0), 1: (np.arange(0, 6000, 2.0), 0), 5: (depf, 0), 3: (depf, 3), 2: (depf, 2), 0: (depf, 1)}   # zm -> (zin, PGR_OPT_DEPTH_SEARCH)
+    X_SMALL, S_SMALL, N_SMALL = 30e3, 13, 200
+    X_BIG, S_BIG, N_BIG = 6e3, 5, 8 * 256 * 64 + 65
+    every = 300
+    seen = set()
+
+    def env_for(zin, lds):
+        nr = 7
+        r = np.linspace(0.0, 40e3, nr)
+        cin = np.array([munk(zin, 1300.0 + (0.0 if lds else 4e-3 * ri)) for ri in r])
+        cpin = np.gradient(cin, zin, axis=1, edge_order=1)
+        return [cin, cpin, r, zin, np.full(nr, 4800.0), r.copy(), np.zeros(nr)]
+
+    def launch(env, y0, x1, S, sv, want):
+        fan = DeviceFan(env, y0, 0.0, x1, S, save=(sv != 0), sample_major=True, exact_samples=(sv == 2), sample_blocked=(sv == 3))
+        fan.run(); torch.cuda.synchronize()
+        li = env.last_instance()
+        got = (li["lds_tab"], li["zm"], li["save"], li["persist"])
+        assert got == want, (got, want, li)
+        seen.add(got)
+        out = {k: getattr(fan, k).cpu().numpy() for k in ("end", "n_bott", "n_surf", "status", "n_steps", "n_rej")}
+        if sv:
+            out.update({k.lower() if k != "T" else k: fan.rows(getattr(fan, k)).cpu().numpy().T.copy() for k in ("T", "Z", "P")})
+        return out
+
+    def check(out, o, sub, sv, label):
+        t = {k: (v[sub] if v.ndim and len(v) == len(out["status"]) else v) for k, v in out.items()}
+        if sv:
+            assert_bit_parity(t, o, label=label, samples=(sv == 2))
+        else:
+            assert np.array_equal(t["status"], o["status"]), label
+            ok = o["status"] == 0
+            end_o = np.stack([o["T"][:, -1], o["z"][:, -1], o["p"][:, -1]], 1)
+            for a_, b_ in ((t["end"], end_o), (t["n_bott"], o["n_bott"]), (t["n_surf"], o["n_surf"]),
+                           (t["n_steps"].astype(np.int64), o["n_steps"]), (t["n_rej"].astype(np.int64), o["n_rej"])):
+                assert np.array_equal(a_[ok], b_[ok]), label
+
+    for lds in (1, 0):
+        for zm, (zin, search) in grids.items():
+            arrs = env_for(zin, lds)
+            env = lib.EnvHandle(*arrs)
+            env.set_option("depth_search", search)
+            y0s = y0_for(oracle, arrs, 900.0, 0.0, np.linspace(-19.5, 19.5, N_SMALL))
+            y0b = y0_for(oracle, arrs, 900.0, 0.0, np.linspace(-19.5, 19.5, N_BIG))
+            sub = np.arange(0, N_BIG, every)
+            o_small = oracle.shoot_fan(*arrs, y0s, 0.0, X_SMALL, S_SMALL, math=oracle.MATH_CR)
+            o_big = oracle.shoot_fan(*arrs, y0b[sub], 0.0, X_BIG, S_BIG, math=oracle.MATH_CR)
+            assert ((o_small["n_bott"] + o_small["n_surf"]) > 0).sum() > 20 and ((o_big["n_bott"] + o_big["n_surf"]) > 0).sum() > 20
+            for sv in ((0, 1, 2) if lds else (0, 1, 2, 3)):
+                out = launch(env, y0s, X_SMALL, S_SMALL, sv, (lds, zm, sv, 0))
+                check(out, o_small, np.arange(N_SMALL), sv, f"<{lds},{zm},{sv},0>")
+                if sv != 2:
+                    out = launch(env, y0b, X_BIG, S_BIG, sv, (lds, zm, sv, 1))
+                    check(out, o_big, sub, sv, f"<{lds},{zm},{sv},1>")
+            env.close()
+    want_all = {(lds, zm, sv, pv) for lds in (1, 0) for zm in range(6) for sv in ((0, 1, 2) if lds else (0, 1, 2, 3))
+                for pv in ((0,) if sv == 2 else (0, 1))}
+    assert seen == want_all and len(seen) == 72, sorted(want_all - seen)
+    with capsys.disabled():
+        print(f"\n{len(seen)} / {len(want_all)} reachable instances of pgr_fan_kernel launched and bit-identical to the oracle")
+
+
 def test_api_callers_of_hbm_table_environments_get_the_sample_blocked_kernel(lib):
     """pgr_shoot_fan (sample-major) and the fan handles integrate trajectory fans of environments whose tables stay in HBM / L2
     with the sample-blocked kernel and un-block in the pass that squeezes dropped rays out (PGR_OPT_API_BLOCKED 1, the
