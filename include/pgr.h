@@ -220,8 +220,8 @@ int pgr_eigen_refine_depths(pgr_env* env, int64_t nbk, const double* th1, const 
  * shoot_ray(theta) of the same angle all start from the SAME bits, the reference's.  Costs one small D2H + H2D per iteration.
  * slowness == NULL: the device's correctly rounded sine, as pgr_eigen_refine_depths.
  * The callback runs on the calling thread INSIDE the search: the environment's workspace lock is held and its buffers are in
- * use, so it must NOT call back into the same pgr_env (pgr_shoot_fan, pgr_eigen_refine*, pgr_fan_*, pgr_env_destroy on `env`
- * would deadlock or reallocate the workspace under the loop); other environments are fine.  It must not throw / longjmp
+ * use, so it must NOT call back into the same environment: pgr_shoot_fan, pgr_eigen_refine*, pgr_fan_*, pgr_env_destroy on `env`
+ * would deadlock or reallocate the workspace under the loop; other environments are fine.  It must not throw / longjmp
  * through the C frames. */
 typedef void (*pgr_slowness_fn)(const double* ode_angles_deg, int64_t n, double* p0_out, void* user);
 int pgr_eigen_refine_depths_fn(pgr_env* env, int64_t nbk, const double* th1, const double* th2, const double* z1,

@@ -68,13 +68,17 @@ def y0_for(oracle, arrs, source_depth, source_range, theta_ode):
     return np.stack([np.zeros_like(th), np.full_like(th, source_depth), np.sin(np.radians(th)) / c0], 1)
 
 
-def oracle_selfnoise(oracle, arrs, y0, x0, x1, S, **kw):
-    """The oracle re-run under 1-ulp perturbations of p0 (both ways) and of rtol (both ways)."""
+def oracle_selfnoise(oracle, arrs, y0, x0, x1, S, ulps=(1,), **kw):
+    """The oracle re-run under k-ulp perturbations of p0 (both ways, k in `ulps`; default 1 ulp) and 1-ulp perturbations of
+    rtol (both ways).  (`ulps=(1, 2, 3)` is how the reference's own self-noise was sampled for the golden vectors g11-g13,
+    `selfnoise_end`: seven end states per ray.)"""
     outs = []
-    for d in (-1, 1):
-        y = y0.copy()
-        y[:, 2] = np.nextafter(y[:, 2], d * np.inf)
-        outs.append(oracle.shoot_fan(*arrs, y, x0, x1, S, **kw))
+    for k in ulps:
+        for d in (-1, 1):
+            y = y0.copy()
+            for _ in range(int(k)):
+                y[:, 2] = np.nextafter(y[:, 2], d * np.inf)
+            outs.append(oracle.shoot_fan(*arrs, y, x0, x1, S, **kw))
     rt = kw.get("rtol", 1e-9)
     kw2 = {k: v for k, v in kw.items() if k != "rtol"}
     for d in (0.0, 1.0):

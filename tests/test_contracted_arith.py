@@ -21,6 +21,10 @@ import pytest
 from helpers import load, env_from, tiled_env, munk_arrays
 
 pytestmark = pytest.mark.gpu
+# rule (B)'s self-noise for this mode: the oracle under +-1, 2, 3-ulp perturbations of p0 (+ rtol +-1 ulp) -- the sampling the
+# reference's own self-noise was recorded with in the golden vectors (seven end states per ray).  Contracted arithmetic is one
+# more draw from that noise: against a spread estimated from +-1 ulp alone (four runs) 2 of g11's 288 rays exceeded 10 x.
+NOISE_ULPS = (1, 2, 3)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -66,38 +70,38 @@ def test_contracted_library_is_the_one_loaded(clib, capsys):
 
 
 def test_contracted_meets_rule_b_on_the_reference_vectors(clib):
-    """Rule (B) only (bit_parity=False): the contracted fan against the vectors the reference itself produced."""
+    """Rule (B) only (bit_parity=False, noise_ulps=NOISE_ULPS): the contracted fan against the vectors the reference itself produced."""
     from test_hip_parity import golden_check
     g = load("g2_munk_100km.npz")
-    golden_check(clib, g, tiled_env(g), 0.0, 100e3, 101, label="g2 [contracted]", bit_parity=False)
+    golden_check(clib, g, tiled_env(g), 0.0, 100e3, 101, label="g2 [contracted]", bit_parity=False, noise_ulps=NOISE_ULPS)
     g = load("g3_munk_1000km.npz")
-    golden_check(clib, g, tiled_env(g), 0.0, 1000e3, 101, label="g3 [contracted]", bit_parity=False)
+    golden_check(clib, g, tiled_env(g), 0.0, 1000e3, 101, label="g3 [contracted]", bit_parity=False, noise_ulps=NOISE_ULPS)
     g = load("g9_irregular_grids.npz")
     golden_check(clib, g, env_from(g), 1e3, 69e3, 61, prefix="t9_", rtol=1e-9, label="g9 [contracted]", strict_bouncing=False,
-                 bit_parity=False)
+                 bit_parity=False, noise_ulps=NOISE_ULPS)
     g = load("g4_range_dependent.npz")
     floor = dict(T=1e-6, z=1e-2, p=1e-7)
     golden_check(clib, g, env_from(g), 10e3, 90e3, 81, prefix="fwd_", label="g4 fwd [contracted]", abs_floor=floor,
-                 strict_bouncing=False, bit_parity=False)
+                 strict_bouncing=False, bit_parity=False, noise_ulps=NOISE_ULPS)
     g = load("g5_const_c.npz")
-    golden_check(clib, g, env_from(g), 0.0, 30e3, 60, label="const c [contracted]", bit_parity=False)
+    golden_check(clib, g, env_from(g), 0.0, 30e3, 60, label="const c [contracted]", bit_parity=False, noise_ulps=NOISE_ULPS)
     g = load("g5_flatearth.npz")
-    golden_check(clib, g, env_from(g), 0.0, 100e3, 101, label="flat earth [contracted]", strict_bouncing=False, bit_parity=False)
+    golden_check(clib, g, env_from(g), 0.0, 100e3, 101, label="flat earth [contracted]", strict_bouncing=False, bit_parity=False, noise_ulps=NOISE_ULPS)
 
 
 def test_contracted_meets_rule_b_at_the_headline_range(clib):
     from test_hip_parity import golden_check
     from test_oracle_golden import end_state_check
     g = load("g11_munk_1000km_288.npz")
-    out = golden_check(clib, g, tiled_env(g), 0.0, 1000e3, 101, label="g11 [contracted]", bit_parity=False)
+    out = golden_check(clib, g, tiled_env(g), 0.0, 1000e3, 101, label="g11 [contracted]", bit_parity=False, noise_ulps=NOISE_ULPS)
     print("g11 end states [contracted]:", end_state_check(g, out, "g11"))
     g = load("g12_config2_128.npz")
     arrs = munk_arrays(float(g["r_max"]), nr=int(g["nr"]), sofar_slope=float(g["sofar_slope"]))
-    out = golden_check(clib, g, arrs, 0.0, 1000e3, 101, label="g12 [contracted]", bit_parity=False)
+    out = golden_check(clib, g, arrs, 0.0, 1000e3, 101, label="g12 [contracted]", bit_parity=False, noise_ulps=NOISE_ULPS)
     print("g12 end states [contracted]:", end_state_check(g, out, "g12"))
     for tag, x1 in (("100km", 100e3), ("1000km", 1000e3)):
         g = load(f"g13_default_env_{tag}.npz")
-        out = golden_check(clib, g, tiled_env(g), 0.0, x1, 101, label="g13 " + tag + " [contracted]", bit_parity=False)
+        out = golden_check(clib, g, tiled_env(g), 0.0, x1, 101, label="g13 " + tag + " [contracted]", bit_parity=False, noise_ulps=NOISE_ULPS)
         print(f"g13 {tag} end states [contracted]:", end_state_check(g, out, "g13 " + tag))
 
 

@@ -64,7 +64,8 @@ def test_device_unit_vectors(lib):
 
 
 # ------------------------------------------------------------------ golden fans (reference outputs)
-def golden_check(lib, g, arrs, x0, x1, S, prefix="", label="", abs_floor=None, strict_bouncing=True, bit_parity=True, **kw):
+def golden_check(lib, g, arrs, x0, x1, S, prefix="", label="", abs_floor=None, strict_bouncing=True, bit_parity=True,
+                 noise_ulps=(1,), **kw):
     """HIP against vectors the REFERENCE itself produced (statistical policy (B) of helpers.py) and,
     on the same inputs, against the oracle bit for bit (A).  (`bit_parity=False`: rule (B) alone -- what
     tests/test_contracted_arith.py asks of the PGR_ARITH=contracted library, which makes no bit-parity claim.)"""
@@ -78,7 +79,7 @@ def golden_check(lib, g, arrs, x0, x1, S, prefix="", label="", abs_floor=None, s
                n_surf=g[prefix + "n_surf"], status=np.where(ok, 0, -1), xi=o["xi"])
     test = dict(out)
     test["status"] = np.where(out["status"] == 0, 0, -1)
-    noise = oracle_selfnoise(oracle, arrs, g[prefix + "y0"], x0, x1, S, **kw)
+    noise = oracle_selfnoise(oracle, arrs, g[prefix + "y0"], x0, x1, S, ulps=noise_ulps, **kw)
     for n in noise:
         n["status"] = np.where(n["status"] == 0, 0, -1)
     worst = assert_fan_parity(test, ref, noise_runs=noise,
