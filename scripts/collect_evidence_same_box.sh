@@ -13,6 +13,8 @@ timeout -k 10 300 python bench.py --flat-earth --no-cpu-baseline --no-eigenray -
 timeout -k 10 300 python bench.py --rays 1000000 --no-save --no-cpu-baseline --no-eigenray --no-legs > $O/bench_line_rays_1e6.json 2>> $O/bench.err; echo "rc $?"
 bash scripts/collect_profiles.sh $TAG > $O/collect.log 2>&1; echo "collect_profiles rc $?"
 bash scripts/collect_profiles_r05.sh $TAG > $O/collect_r05.log 2>&1; echo "collect_profiles_r05 rc $?"
+bash scripts/collect_profiles_r06.sh $TAG > $O/collect_r06.log 2>&1; echo "collect_profiles_r06 rc $?"
+timeout -k 10 300 python bench.py --rays 1000000 --no-cpu-baseline --no-eigenray --no-legs > $O/bench_line_rays_1e6_traj.json 2>> $O/bench.err; echo "rc $?"
 python - <<'PY'
 import json, glob, csv, os
 d = json.load(open(os.path.join("gpurun_out", os.environ.get("TAGX", ""), "bench_line.json"))) if False else None

@@ -89,7 +89,20 @@ if fe is not None and wr is not None:
     if sq:
         out["sample-nosave@1000000-sq_counters"] = sq
         out["sample-nosave@1000000"]["valu_wave_instructions_per_launch"] = sq.get("SQ_INSTS_VALU")
-for what, name in (("1e6", "1e6"), ("lone", "lone_wave"), ("api2", "api_config2")):
+# ---- round 6: the 1e6-ray fan WITH S = 1001 trajectories (pgr_fan_kernel<true, 4, 1, true>, 24 GB of samples)
+fe, wr = fan_counters(f"{tag}_1e6traj_FETCH_SIZE").get("FETCH_SIZE"), fan_counters(f"{tag}_1e6traj_WRITE_SIZE").get("WRITE_SIZE")
+if fe is not None and wr is not None:
+    out["sample@1000000"] = {"rays": 1000000, "FETCH_SIZE_KB": fe, "WRITE_SIZE_KB": wr, "hbm_gb_per_launch": (2 * fe + wr) * 1024 / 1e9,
+                             "sample_gb": 1000000 * 1001 * 24 / 1e9,
+                             "note": f"profiles/{rnd}_traffic.json: rocprofv3 PMC passes (FETCH_SIZE x 2 per the gfx950 correction + WRITE_SIZE), "
+                                     "fan kernel pgr_fan_kernel<true, 4, 1, true> (persistent waves, S = 1001 trajectories), last dispatch",
+                             "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --rays 1000000 "
+                                        "--steps 2 --warmup 1 --no-cpu-baseline --no-eigenray --no-legs"}
+    sq = fan_counters(f"{tag}_1e6traj_sq")
+    if sq:
+        out["sample@1000000-sq_counters"] = sq
+        out["sample@1000000"]["valu_wave_instructions_per_launch"] = sq.get("SQ_INSTS_VALU")
+for what, name in (("1e6", "1e6"), ("1e6traj", "1e6_traj"), ("nosave", "end_state"), ("lone", "lone_wave"), ("api2", "api_config2")):
     st = glob.glob(os.path.join(G, f"{tag}_{what}_stats", "*", "*_kernel_stats.csv"))
     if st:
         shutil.copy(st[0], os.path.join(ROOT, "profiles", f"{rnd}_kernel_stats_{name}.csv"))
