@@ -1,5 +1,5 @@
 """PGR_SAMPLE_BLOCKED against the row layout over the random environments of tests/helpers.random_case that take the HBM-table
-path (range-dependent sound speed): every ray, every sample, NaN columns, padding rows pre-filled.  usage: python scripts/fuzz_blocked.py"""
+path (range-dependent sound speed): every ray, every sample, NaN columns, padding rows pre-filled.  usage: python scripts/fuzz_blocked.py [first:last]   (default 20000:20600)"""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -8,7 +8,8 @@ from helpers import random_case, y0_for
 from pygenray_amd import _lib
 from pygenray_amd.device_fan import DeviceFan
 n_env = n_hbm = 0
-for seed in range(20000, 20600):
+_A, _B = (int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "20000:20600").split(":"))
+for seed in range(_A, _B):
     arrs, (src, x0, th), kw, desc = random_case(seed)
     env = _lib.EnvHandle(*arrs)
     n_env += 1
