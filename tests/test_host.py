@@ -697,6 +697,56 @@ def test_round5_profiles_and_bench_line():
     assert reh["eigenray_sharded"]["fan_rays_per_gpu"] == 200_000 and "REHEARSAL" in reh["config"]["sharding"]
 
 
+def test_round6_profiles_and_bench_line():
+    """profiles/r06_*: the committed bench line, the rocprofv3 summaries and the PMC passes name ONE binary; the line carries the
+    legs round 6 added (headline end state, per-step kernel times); rocprofv3's per-call durations agree with the line's HIP
+    events once the cold warm-up calls are left out; the 1e6-ray trajectory instance writes ~1.08 x its samples."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    P = os.path.join(root, "profiles")
+    tr = json.load(open(os.path.join(P, "r06_traffic.json")))
+    d = json.load(open(os.path.join(P, "r06_bench_line.json")))
+    sha = tr["device_code_sha256"]
+    assert len(sha) == 64 and d["device_code_sha256"] == sha and tr["build"].startswith("layout: relaid")
+    for name in ("config2", "config2_blocked", "flatearth", "rays_1e6", "rays_1e6_traj"):
+        x = json.load(open(os.path.join(P, f"r06_bench_line_{name}.json")))
+        assert x["device_code_sha256"] == sha, name
+    for m in re.finditer(r"device_code_sha256 ([0-9a-f]{64})", open(os.path.join(P, "r06_fuzz_sweeps.txt")).read()):
+        assert m.group(1) == sha
+    # the driver's line: metric / workload of BASELINE.json, roofline + cpu_baseline, the legs
+    assert d["metric"] == json.load(open(os.path.join(root, "BASELINE.json")))["metric"] and d["dtype"] == "f64" and d["vs_baseline"] is None
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert 0.30 < r["frac"] < 0.34 and r["traffic"] is not None and 2.4 < r["traffic_gb_per_launch"] < 2.8
+    each = r["kernel_ms_each"]
+    assert len(each) == d["steps"] == 20 and abs(sum(each) / len(each) - r["kernel_ms"]) < 1e-3
+    assert r["kernel_ms"] <= d["ms_per_step"] <= 1.02 * r["kernel_ms"]
+    assert abs(d["value"] - d["config"]["ray_steps_per_pass"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
+    assert set(d["legs"]) == {"flatearth_default", "range_dependent", "rays_1e6", "headline_end_state", "api", "api_config2", "fma_contracted"}
+    he = d["legs"]["headline_end_state"]
+    assert he["bytes_per_ray_step"] == 80.0 and he["kernel_ms"] < r["kernel_ms"] and he["ray_steps"] == d["config"]["ray_steps_per_pass"]
+    assert d["legs"]["rays_1e6"]["end_state"]["frac"] >= 0.40 and d["legs"]["rays_1e6"]["trajectories"]["frac"] >= 0.40
+    assert d["lone_wave_ms"]["trajectories"] < r["kernel_ms"]          # the fan cannot beat its steepest wave
+    # rocprofv3 of the same commands: the instances, and per-call durations that agree with the HIP events once warm
+    for v, tag in (("", "<true, 4, 1, false>"), ("_end_state", "<true, 4, 0, false>"), ("_flatearth", "<true, 5, 1, false>"),
+                   ("_rangedep", "<false, 4, 1, false>"), ("_rangedep_blocked", "<false, 4, 3, false>"), ("_1e6", "<true, 4, 0, true>"),
+                   ("_1e6_traj", "<true, 4, 1, true>"), ("_api_config2", "<false, 4, 3, false>")):
+        assert "pgr_fan_kernel" + tag in open(os.path.join(P, f"r06_kernel_stats{v}.csv")).read(), v
+    kc = json.load(open(os.path.join(P, "r06_kernel_calls.json")))
+    head = [e for e in kc["stats"] if "<true, 4, 1, false>" in e["kernel"]][0]
+    assert head["n_calls"] == 12 and head["stats_mean_ms"] >= head["warm_mean_ms"] and abs(head["warm_mean_ms"] - r["kernel_ms"]) < 0.015 * r["kernel_ms"]
+    big = [e for e in kc["1e6traj_stats"] if "<true, 4, 1, true>" in e["kernel"]][0]
+    x = json.load(open(os.path.join(P, "r06_bench_line_rays_1e6_traj.json")))
+    assert abs(big["warm_mean_ms"] - x["roofline"]["kernel_ms"]) < 0.02 * big["warm_mean_ms"] and x["roofline"]["frac"] >= 0.42
+    assert x["roofline"]["traffic"] is not None and x["roofline"]["kernel"].startswith("pgr_fan_kernel<true, 4, 1, true>")
+    t6 = tr["sample@1000000"]
+    assert t6["rays"] == 1000000 and 1.0 < t6["WRITE_SIZE_KB"] * 1024 / (1e6 * 1001 * 24) < 1.15
+    # the narrow-wave proxy's record (verdict r5 item 1): baseline, lone packets, re-dealt fans, every run bit-equal
+    txt = open(os.path.join(P, "r06_narrow_wave_proxy.txt")).read()
+    assert "baseline save=1" in txt and "lone steepest packet, 16 rays" in txt and txt.count("end states bit-equal True") >= 20 and "bit-equal False" not in txt
+
+
 def test_eval_cache_fingerprint_is_cheap_and_sees_in_place_edits():
     """host_physics._fingerprint (the content check of the tables kept on the device for point-by-point derivsrd / event
     calls): whole-array hashes up to 1 MB, a strided sample beyond -- an in-place edit of a whole table, of a row, of a
