@@ -746,6 +746,24 @@ def test_sample_blocked_layout_holds_the_same_bits_as_the_row_layout(lib):
     arrs3 = bench.munk_tables(1000e3, nr=101, sofar_slope=2e-4)[1]
     o = both(arrs3, fan_y0(arrs3, 1000.0, 0.0, -np.linspace(-20, 20, 100_000)), 1000e3, 1001)
     assert (o[4] != 0).sum() > 100 and int(o[5][o[4] == 0].sum()) > 1.2e8
+    # round 6: the blocked layout is what DeviceFan picks BY ITSELF for an HBM-table environment (pgr_env_query(env, 8)) -- and
+    # rows for an LDS-table one, for the SciPy sample order and for ray-major output; api_blocked = 0 turns the choice off
+    env_h, env_l = lib.EnvHandle(*arrs), lib.EnvHandle(*munk_arrays(100e3))
+    assert env_h.blocked_layout and not env_l.blocked_layout
+    auto = DeviceFan(env_h, y0[:130], 0.0, 300e3, 10, save=True, sample_major=True)
+    rows_ = DeviceFan(env_h, y0[:130], 0.0, 300e3, 10, save=True, sample_major=True, sample_blocked=False)
+    assert auto.sample_blocked and tuple(auto.T.shape) == (3, 130, 4) and not rows_.sample_blocked
+    auto.run(); rows_.run(); torch.cuda.synchronize()
+    for k in ("T", "Z", "P"):
+        assert np.array_equal(auto.rows(getattr(auto, k)).cpu().numpy(), getattr(rows_, k).cpu().numpy(), equal_nan=True)
+    assert env_h.last_instance()["save"] == 1      # (the row-layout fan ran last)
+    assert not DeviceFan(env_l, y0[:64], 0.0, 100e3, 10, save=True, sample_major=True).sample_blocked
+    assert not DeviceFan(env_h, y0[:64], 0.0, 300e3, 10, save=True, sample_major=True, exact_samples=True).sample_blocked
+    assert not DeviceFan(env_h, y0[:64], 0.0, 300e3, 10, save=True, sample_major=False).sample_blocked
+    assert not DeviceFan(env_h, y0[:64], 0.0, 300e3, 10, save=False, sample_major=True).sample_blocked
+    env_h.set_option("api_blocked", 0)
+    assert not env_h.blocked_layout and not DeviceFan(env_h, y0[:64], 0.0, 300e3, 10, save=True, sample_major=True).sample_blocked
+    env_h.close(); env_l.close()
     # refused: an LDS-table environment; the SciPy sample order; ray-major output
     env1 = lib.EnvHandle(*munk_arrays(100e3))
     y1 = y0_for(oracle, munk_arrays(100e3), 1000.0, 0.0, np.linspace(-5, 5, 64))
