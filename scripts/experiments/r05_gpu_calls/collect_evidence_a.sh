@@ -1,6 +1,6 @@
 #!/bin/bash
 # Evidence, part A (one gpurun call, ~12 min): the GPU suite, persistent-wave modes, every rocprofv3 pass, wave / service timing.
-# usage: bash scripts/collect_evidence_a.sh <tag>      then: python scripts/summarize_profiles.py <tag> rNN ; python scripts/summarize_evidence.py <tag> rNN
+# usage: bash scripts/experiments/r05_gpu_calls/collect_evidence_a.sh <tag>      then: python scripts/summarize_profiles.py <tag> rNN ; python scripts/experiments/r05_gpu_calls/summarize_evidence.py <tag> rNN
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-ev}
 cd $R
