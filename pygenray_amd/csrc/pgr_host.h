@@ -81,7 +81,9 @@ struct pgr_env {
     size_t max_lds = 64 * 1024;
     // the fan-kernel instance and launch shape of the LAST pgr_shoot_fan_device on this environment (pgr_debug_last_instance:
     // the test that walks every instance asserts that it launched the one it meant to)
-    int last_instance[8] = {-1, -1, -1, -1, 0, 0, 0, 0};
+    // (atomics: two host threads may launch on one environment; the record is a diagnostic, each field is whole)
+    std::atomic<int> last_instance[8];
+    pgr_env() { for (int q = 0; q < 8; q++) last_instance[q].store(q < 4 ? -1 : 0, std::memory_order_relaxed); }
 };
 
 extern "C" const char* pgr_last_error(void) { return g_err.c_str(); }

@@ -263,7 +263,7 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
 #define PGR_LAUNCH2(LT, ZMV, SV, PV)                                                                 \
     do {                                                                                             \
         { const int li_[8] = {(int)(LT), (ZMV), (SV), (int)(PV), (int)blocks, threads, (int)lds, a.n_queue_tail};              \
-          for (int q_ = 0; q_ < 8; q_++) env->last_instance[q_] = li_[q_]; }                         \
+          for (int q_ = 0; q_ < 8; q_++) env->last_instance[q_].store(li_[q_], std::memory_order_relaxed); } \
         if (lds > 64 * 1024)                                                                         \
             HIPCHK(hipFuncSetAttribute((const void*)pgr_fan_kernel<LT, ZMV, SV, PV>,                 \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));       \
@@ -308,7 +308,7 @@ extern "C" int pgr_shoot_fan_device(pgr_env* env, const double* y0, int64_t N, d
 extern "C" int pgr_debug_last_instance(const pgr_env* env, int32_t out[8])
 {
     if (!env || !out) return fail("pgr_debug_last_instance: null argument");
-    for (int q = 0; q < 8; q++) out[q] = env->last_instance[q];
+    for (int q = 0; q < 8; q++) out[q] = env->last_instance[q].load(std::memory_order_relaxed);
     return 0;
 }
 
