@@ -711,8 +711,15 @@ def test_round6_profiles_and_bench_line():
     for name in ("config2", "config2_blocked", "flatearth", "rays_1e6", "rays_1e6_traj"):
         x = json.load(open(os.path.join(P, f"r06_bench_line_{name}.json")))
         assert x["device_code_sha256"] == sha, name
-    for m in re.finditer(r"device_code_sha256 ([0-9a-f]{64})", open(os.path.join(P, "r06_fuzz_sweeps.txt")).read()):
-        assert m.group(1) == sha
+    for f in ("r06_fuzz_sweeps.txt", "r06_bitparity_S1001.txt", "r06_bitparity_1e6_rays.txt", "r06_final_checks.txt"):
+        found = re.findall(r"device_code_sha256 ([0-9a-f]{64})", open(os.path.join(P, f)).read())
+        assert found and all(v == sha for v in found), f
+    # ALL rays of the three benched workloads (x 1001 samples) and ALL 1e6 rays of the configs[3] / [4] fan, this round's library
+    bp = open(os.path.join(P, "r06_bitparity_S1001.txt")).read()
+    assert bp.count("status equal: True") == 3 and len(re.findall(r"all ok\s+n=\s*\d+\s+bit-equal: end state 1\.00000  n_steps 1\.00000  n_rej 1\.00000  bounces 1\.00000  all 1001 samples \(SciPy order\) 1\.00000", bp)) == 3
+    assert bp.count("end states bit-equal True; step / bounce counts equal True") == 3 and "equal False" not in bp and "equal: False" not in bp
+    b6 = open(os.path.join(P, "r06_bitparity_1e6_rays.txt")).read()
+    assert "rays 1000000" in b6 and re.search(r"all ok\s+n=999535\s+bit-equal: end state 1\.00000  n_steps 1\.00000  n_rej 1\.00000  bounces 1\.00000", b6) and "equal: False" not in b6
     # the driver's line: metric / workload of BASELINE.json, roofline + cpu_baseline, the legs
     assert d["metric"] == json.load(open(os.path.join(root, "BASELINE.json")))["metric"] and d["dtype"] == "f64" and d["vs_baseline"] is None
     r = d["roofline"]
