@@ -579,6 +579,11 @@ struct Ctx {
             // of two pieces of two rows nz x 16 B apart; 4 x the table.  Measured, not kept: LABNOTES round 6)
             const GlobalTab row = (GlobalTab)h_tab + ((size_t)i * (size_t)(h_nz - 1) + (size_t)j) * 4;
             const d2v t00 = row[0], t01 = row[1], t10 = row[2], t11 = row[3];
+#elif defined(PGR_ROW_PAIRS)
+            // (experiment, round 6: rows i and i + 1 interleaved node by node, [nr - 1][nz][2]: the four corner nodes are 64
+            // contiguous bytes as with the cell records, for 2 x the table instead of 4 x.  Measured: LABNOTES round 6)
+            const GlobalTab row = (GlobalTab)h_tab + ((size_t)i * (size_t)h_nz + (size_t)j) * 2;
+            const d2v t00 = row[0], t10 = row[1], t01 = row[2], t11 = row[3];
 #else
             const GlobalTab row = (GlobalTab)h_tab + (size_t)i * h_row_stride + j;
             const d2v t00 = row[0], t01 = row[1], t10 = row[h_row_stride], t11 = row[h_row_stride + 1];

@@ -291,6 +291,16 @@ extern "C" int pgr_env_create(pgr_env** out, int device, const double* cin, cons
             }
         tab.swap(rec);
     }
+#elif defined(PGR_ROW_PAIRS)
+    if (!indep) {   // (experiment: {c, cp} of (i, j) and (i + 1, j) side by side, see Ctx::fetch_nodes)
+        std::vector<double2> rec((size_t)(nr - 1) * (size_t)nz * 2);
+        for (int64_t i = 0; i + 1 < nr; i++)
+            for (int64_t j = 0; j < nz; j++) {
+                rec[((size_t)i * (size_t)nz + (size_t)j) * 2] = tab[i * nz + j];
+                rec[((size_t)i * (size_t)nz + (size_t)j) * 2 + 1] = tab[(i + 1) * nz + j];
+            }
+        tab.swap(rec);
+    }
 #endif
     rc |= upload(e, tab.data(), tab.size(), &d.tab);
     rc |= upload(e, rin, (size_t)nr, &d.rin);
